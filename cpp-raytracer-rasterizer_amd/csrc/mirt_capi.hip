@@ -1,0 +1,479 @@
+// mirt_capi.hip -- the C-ABI of include/mirt.h on top of the HIP kernels.  Owns the device scene, the
+// library stream, staging buffers and the per-call statistics.  No CPU fallback: without a gfx950 device
+// every compute entry point returns MIRT_ERR_NO_DEVICE.
+#include "rt_common.hpp"
+#include "raster_common.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+
+namespace mirt {
+
+// kernels (rt_kernels.hip, raster_kernels.hip)
+__global__ void k_prep_origin(const float *, int, const float *, OriginRow *, OriginRow *, uint32_t *);
+template <int P> __global__ void k_rt_brute(const RtFrame);
+int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
+
+namespace {
+
+char g_err[512] = "no error";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(MIRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+enum { EV_CALL0 = 0, EV_CALL1 = 1, EV_K0 = 2, EV_COUNT = 2 + 2 * 8 };
+
+struct Ctx {
+    bool init = false;
+    bool profiling = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    bool ev_used[8] = {};
+
+    // scene
+    int n = 0;
+    float *d_tris = nullptr;
+    uint8_t *d_culled = nullptr;
+    OriginRow *d_cam_tab = nullptr;
+    OriginRow *d_light_tab = nullptr;
+    int light_tab_lights = 0;
+    float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
+    uint32_t *d_flags = nullptr;                 // [0] = unsafe, [2..3] = hit counter (u64)
+    bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
+    uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
+
+    // staging for the host-buffer entry points
+    void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr;
+    size_t cap_px = 0;
+    RasterScratch raster;
+
+    // statistics of the last call
+    mirt_stats stats = {};
+    bool stats_pending = false;
+    uint64_t pending_primary = 0;
+    int pending_nlights = 0;
+    bool pending_is_rt = false;
+};
+
+Ctx g;
+
+int need_init()
+{
+    if (!g.init) return fail(MIRT_ERR_NOT_INITIALISED, "mirt_init has not been called (or failed)");
+    return MIRT_OK;
+}
+
+template <typename T>
+int dev_realloc(T **p, size_t count)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) return MIRT_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+    if (e != hipSuccess) { *p = nullptr; return fail(MIRT_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e)); }
+    return MIRT_OK;
+}
+
+int ensure_staging(size_t px, bool rgb, bool index, bool zinv)
+{
+    if (px > g.cap_px) {
+        for (void **p : { &g.d_xrgb, &g.d_rgb, &g.d_index, &g.d_zinv }) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        g.cap_px = 0;
+    }
+    auto grow = [&](void **p, size_t bytes) -> int {
+        if (*p) return MIRT_OK;
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) { *p = nullptr; return fail(MIRT_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+        return MIRT_OK;
+    };
+    int rc;
+    if ((rc = grow(&g.d_xrgb, px * 4))) return rc;
+    if (rgb && (rc = grow(&g.d_rgb, px * 12))) return rc;
+    if (index && (rc = grow(&g.d_index, px * 4))) return rc;
+    if (zinv && (rc = grow(&g.d_zinv, px * 4))) return rc;
+    if (px > g.cap_px) g.cap_px = px;
+    return MIRT_OK;
+}
+
+bool finite_below(const float *p, int n, float lim)
+{
+    for (int i = 0; i < n; i++) if (!(fabsf(p[i]) < lim)) return false;
+    return true;
+}
+
+int check_view(const mirt_view *v, const mirt_light *lights, int nlights, const float *indirect)
+{
+    if (!v || !indirect) return fail(MIRT_ERR_INVALID_ARGUMENT, "view / indirect must not be NULL");
+    if (v->width < 1 || v->height < 1 || v->width > 32768 || v->height > 32768)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "frame size %dx%d out of range [1,32768]", v->width, v->height);
+    if (nlights < 0 || nlights > MIRT_MAX_LIGHTS) return fail(MIRT_ERR_INVALID_ARGUMENT, "nlights %d out of range [0,%d]", nlights, MIRT_MAX_LIGHTS);
+    if (nlights > 0 && !lights) return fail(MIRT_ERR_INVALID_ARGUMENT, "lights must not be NULL when nlights > 0");
+    return MIRT_OK;
+}
+
+void k_begin(int k) { if (g.profiling) { (void)hipEventRecord(g.ev[EV_K0 + 2 * k], g.stream); g.ev_used[k] = true; } }
+void k_end(int k) { if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * k + 1], g.stream); }
+
+void call_begin()
+{
+    memset(&g.stats, 0, sizeof g.stats);
+    memset(g.ev_used, 0, sizeof g.ev_used);
+    (void)hipEventRecord(g.ev[EV_CALL0], g.stream);
+}
+void call_end() { (void)hipEventRecord(g.ev[EV_CALL1], g.stream); g.stats_pending = true; }
+
+// ---- ray tracer --------------------------------------------------------------------------------------
+
+int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect, int mode,
+               int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if ((rc = check_view(view, lights, nlights, indirect))) return rc;
+    if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
+    if (!d_xrgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "xrgb output must not be NULL");
+    if (y0 < 0 || y1 > view->height || y0 > y1) return fail(MIRT_ERR_INVALID_ARGUMENT, "row band [%d,%d) outside [0,%d)", y0, y1, view->height);
+    if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
+    if (mode != MIRT_RT_AUTO && mode != MIRT_RT_BRUTE && mode != MIRT_RT_BINNED) return fail(MIRT_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+
+    if (nlights > g.light_tab_lights) {
+        if ((rc = dev_realloc(&g.d_light_tab, (size_t)nlights * g.n))) { g.light_tab_lights = 0; return rc; }
+        g.light_tab_lights = nlights;
+    }
+
+    call_begin();
+    g.pending_is_rt = true;
+    g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0);
+    g.pending_nlights = nlights;
+    g.stats.mode_used = MIRT_RT_BRUTE;
+    if (y1 == y0) { call_end(); return MIRT_OK; }
+
+    RtFrame f;
+    memset(&f, 0, sizeof f);
+    f.tris15 = g.d_tris;
+    f.n = g.n;
+    f.cam_tab = g.d_cam_tab;
+    f.light_tab = g.d_light_tab;
+    f.unsafe = g.d_flags;
+    memcpy(f.cam, view->pos, sizeof f.cam);
+    memcpy(f.rot, view->rot, sizeof f.rot);
+    f.focal = view->focal;
+    f.W = view->width;
+    f.H = view->height;
+    f.nlights = nlights;
+    float origins[(1 + MIRT_MAX_LIGHTS) * 3];
+    memcpy(origins, view->pos, 12);
+    for (int k = 0; k < nlights; k++) {
+        memcpy(f.lpos[k], lights[k].pos, 12);
+        memcpy(origins + 3 * (k + 1), lights[k].pos, 12);
+        for (int c = 0; c < 3; c++) f.lcol[k][c] = lights[k].color[c] * lights[k].intensity;   // raytracer.cpp:282
+    }
+    memcpy(f.indirect, indirect, 12);
+    f.y0 = y0; f.y1 = y1; f.row_origin = row_origin;
+    f.xrgb = static_cast<uint32_t *>(d_xrgb);
+    f.pitch_words = pitch_bytes / 4;
+    f.rgb = static_cast<float *>(d_rgb);
+    f.index = static_cast<int32_t *>(d_index);
+    f.hit_count = reinterpret_cast<unsigned long long *>(g.d_flags + 2);
+
+    // The pre-reject filter is proven for finite, moderate operands only (rt_common.hpp); anything else
+    // (absurd coordinates, NaN/Inf) renders through the exact-only path.  Ray directions of the primary
+    // rays are bounded by 3 * max|rot| * max(W, H, |focal|).
+    float rmax = 0.0f;
+    for (int i = 0; i < 9; i++) rmax = fmaxf(rmax, fabsf(view->rot[i]));
+    const float dmax = 3.0f * rmax * fmaxf(fmaxf((float)view->width, (float)view->height), fabsf(view->focal));
+    bool safe = g.scene_finite && finite_below(view->pos, 3, MIRT_SAFE_MAG) && finite_below(view->rot, 9, 1.0e6f) &&
+                (dmax < 1.0e6f) && finite_below(origins, 3 * (1 + nlights), MIRT_SAFE_MAG);
+    const uint32_t flags_init[4] = { safe ? 0u : 1u, 0u, 0u, 0u };
+
+    HIP_TRY(hipMemcpyAsync(g.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
+
+    k_begin(MIRT_K_PREP);
+    hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1 + nlights), dim3(256), 0, g.stream,
+                       g.d_tris, g.n, g.d_origins, g.d_cam_tab, g.d_light_tab, g.d_flags);
+    k_end(MIRT_K_PREP);
+
+    static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 1; return (p == 2) ? 2 : 1; }();
+    const int rows = y1 - y0;
+    const size_t lds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
+    k_begin(MIRT_K_TRACE);
+    if (P == 2)
+        hipLaunchKernelGGL(k_rt_brute<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), lds, g.stream, f);
+    else
+        hipLaunchKernelGGL(k_rt_brute<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), lds, g.stream, f);
+    k_end(MIRT_K_TRACE);
+    HIP_TRY(hipGetLastError());
+    call_end();
+    return MIRT_OK;
+}
+
+int copy_plane_interior(void *dst, int dst_pitch, const void *src, int src_pitch, int W, int H)
+{
+    // rows 1..H-2, columns 1..W-2 only: the reference never writes the 1-pixel border (raytracer.cpp:618-620)
+    if (W < 3 || H < 3) return MIRT_OK;
+    HIP_TRY(hipMemcpy2DAsync(static_cast<char *>(dst) + dst_pitch + 4, dst_pitch,
+                             static_cast<const char *>(src) + src_pitch + 4, src_pitch,
+                             (size_t)(W - 2) * 4, H - 2, hipMemcpyDeviceToHost, g.stream));
+    return MIRT_OK;
+}
+
+}  // namespace
+}  // namespace mirt
+
+using namespace mirt;
+
+// ---- lifetime ----------------------------------------------------------------------------------------
+
+extern "C" int mirt_abi_version(void) { return MIRT_ABI_VERSION; }
+extern "C" const char *mirt_last_error(void) { return g_err; }
+
+extern "C" int mirt_init(int device)
+{
+    if (g.init) {
+        if (g.device == device) return MIRT_OK;
+        mirt_shutdown();
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(MIRT_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(MIRT_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MIRT_ERR_NO_DEVICE, "device %d is %s; the kernels in this library are built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev[i]));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_flags), 16));
+    HIP_TRY(hipMemset(g.d_flags, 0, 16));
+    g.device = device;
+    g.init = true;
+    return MIRT_OK;
+}
+
+extern "C" void mirt_shutdown(void)
+{
+    if (!g.init) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
+                     (void *)g.d_flags, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv })
+        if (p) (void)hipFree(p);
+    raster_scratch_free(g.raster);
+    for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g = Ctx();
+}
+
+extern "C" int mirt_set_profiling(int on)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    g.profiling = on != 0;
+    return MIRT_OK;
+}
+
+extern "C" int mirt_sync(void)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return MIRT_OK;
+}
+
+extern "C" void *mirt_stream(void) { return g.init ? (void *)g.stream : nullptr; }
+
+// ---- scene ------------------------------------------------------------------------------------------
+
+extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int n)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!tris15 || n < 1) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene needs at least one triangle (n = %d)", n);
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.n = 0;
+    if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
+    if ((rc = dev_realloc(&g.d_culled, (size_t)n))) return rc;
+    if ((rc = dev_realloc(&g.d_cam_tab, (size_t)n))) return rc;
+    if ((rc = dev_realloc(&g.d_light_tab, (size_t)0))) return rc;
+    g.light_tab_lights = 0;
+    HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
+    if (culled) HIP_TRY(hipMemcpy(g.d_culled, culled, (size_t)n, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(g.d_culled, 0, (size_t)n));
+    g.scene_finite = true;
+    for (size_t i = 0; i < (size_t)n * 15 && g.scene_finite; i++)
+        if (!(fabsf(tris15[i]) < 1.0e8f)) g.scene_finite = false;   // generous: |coord| < 1e8 keeps cross products < 1e18
+    g.n = n;
+    g.scene_version++;
+    return MIRT_OK;
+}
+
+extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
+    if (n != g.n) return fail(MIRT_ERR_INVALID_ARGUMENT, "cull array has %d entries, scene has %d triangles", n, g.n);
+    if (culled) HIP_TRY(hipMemcpyAsync(g.d_culled, culled, (size_t)n, hipMemcpyHostToDevice, g.stream));
+    else HIP_TRY(hipMemsetAsync(g.d_culled, 0, (size_t)n, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.scene_version++;
+    return MIRT_OK;
+}
+
+extern "C" int mirt_scene_size(void) { return g.init ? g.n : 0; }
+
+// ---- ray tracer -------------------------------------------------------------------------------------
+
+extern "C" int mirt_raytrace_device(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                    int mode, int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes,
+                                    void *d_rgb, void *d_index)
+{
+    return rt_enqueue(view, lights, nlights, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index);
+}
+
+extern "C" int mirt_raytrace(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                             int mode, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb, int32_t *out_index)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if ((rc = check_view(view, lights, nlights, indirect))) return rc;
+    if (!out_xrgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "out_xrgb must not be NULL");
+    if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
+    const int W = view->width, H = view->height;
+    const size_t px = (size_t)W * H;
+    if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, false))) return rc;
+    if ((rc = rt_enqueue(view, lights, nlights, indirect, mode, 0, H, 0, g.d_xrgb, W * 4,
+                         out_rgb ? g.d_rgb : nullptr, out_index ? g.d_index : nullptr))) return rc;
+    if ((rc = copy_plane_interior(out_xrgb, pitch_bytes, g.d_xrgb, W * 4, W, H))) return rc;
+    if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, g.d_rgb, px * 12, hipMemcpyDeviceToHost, g.stream));
+    if (out_index) HIP_TRY(hipMemcpyAsync(out_index, g.d_index, px * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return MIRT_OK;
+}
+
+// ---- rasteriser -------------------------------------------------------------------------------------
+
+static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                          int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_zinv,
+                          void *d_index)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if ((rc = check_view(view, lights, nlights, indirect))) return rc;
+    if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
+    if (!d_xrgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "xrgb output must not be NULL");
+    if (y0 < 0 || y1 > view->height || y0 > y1) return fail(MIRT_ERR_INVALID_ARGUMENT, "row band [%d,%d) outside [0,%d)", y0, y1, view->height);
+    if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
+
+    call_begin();
+    g.pending_is_rt = false;
+    if (y1 == y0) { call_end(); return MIRT_OK; }
+
+    RasterFrame f;
+    memset(&f, 0, sizeof f);
+    f.tris15 = g.d_tris;
+    f.culled = g.d_culled;
+    f.n = g.n;
+    memcpy(f.cam, view->pos, 12);
+    memcpy(f.rot, view->rot, 36);
+    mat3_inverse(view->rot, f.invrot);        // glm::inverse(cameraRot), hoisted out of PixelShader (rasteriser.cpp:559)
+    f.focal = view->focal;
+    f.W = view->width; f.H = view->height;
+    f.nlights = nlights;
+    for (int k = 0; k < nlights; k++) {
+        memcpy(f.lpos[k], lights[k].pos, 12);
+        for (int c = 0; c < 3; c++) f.lcol[k][c] = lights[k].color[c] * lights[k].intensity;   // rasteriser.cpp:576
+    }
+    memcpy(f.indirect, indirect, 12);
+    f.y0 = y0; f.y1 = y1; f.row_origin = row_origin;
+    f.xrgb = static_cast<uint32_t *>(d_xrgb);
+    f.pitch_words = pitch_bytes / 4;
+    f.rgb = static_cast<float *>(d_rgb);
+    f.zinv = static_cast<float *>(d_zinv);
+    f.index = static_cast<int32_t *>(d_index);
+    if ((rc = raster_scratch_ensure(g.raster, g.n, view->width, y1 - y0))) return fail(rc, "raster scratch allocation failed");
+    if (g.profiling) for (int k = MIRT_K_RASTER_SETUP; k <= MIRT_K_CLEAR; k++) g.ev_used[k] = true;
+    if ((rc = launch_raster(f, g.raster, g.scene_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr)))
+        return fail(rc, "rasteriser launch failed: %s", hipGetErrorString(hipGetLastError()));
+    call_end();
+    return MIRT_OK;
+}
+
+extern "C" int mirt_rasterise_device(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                     int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb,
+                                     void *d_zinv, void *d_index)
+{
+    return raster_enqueue(view, lights, nlights, indirect, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_zinv, d_index);
+}
+
+extern "C" int mirt_rasterise(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                              uint32_t *out_xrgb, int pitch_bytes, float *out_rgb, float *out_zinv, int32_t *out_index)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if ((rc = check_view(view, lights, nlights, indirect))) return rc;
+    if (!out_xrgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "out_xrgb must not be NULL");
+    if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
+    const int W = view->width, H = view->height;
+    const size_t px = (size_t)W * H;
+    if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, out_zinv != nullptr))) return rc;
+    if ((rc = raster_enqueue(view, lights, nlights, indirect, 0, H, 0, g.d_xrgb, W * 4, out_rgb ? g.d_rgb : nullptr,
+                             out_zinv ? g.d_zinv : nullptr, out_index ? g.d_index : nullptr))) return rc;
+    // the rasteriser's Update() paints the whole surface (rasteriser.cpp:190): every word is written
+    HIP_TRY(hipMemcpy2DAsync(out_xrgb, pitch_bytes, g.d_xrgb, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, g.stream));
+    if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, g.d_rgb, px * 12, hipMemcpyDeviceToHost, g.stream));
+    if (out_zinv) HIP_TRY(hipMemcpyAsync(out_zinv, g.d_zinv, px * 4, hipMemcpyDeviceToHost, g.stream));
+    if (out_index) HIP_TRY(hipMemcpyAsync(out_index, g.d_index, px * 4, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return MIRT_OK;
+}
+
+// ---- statistics -------------------------------------------------------------------------------------
+
+extern "C" int mirt_get_stats(mirt_stats *out)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!out) return fail(MIRT_ERR_INVALID_ARGUMENT, "out must not be NULL");
+    if (g.stats_pending) {
+        HIP_TRY(hipEventSynchronize(g.ev[EV_CALL1]));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, g.ev[EV_CALL0], g.ev[EV_CALL1]) == hipSuccess) g.stats.gpu_ms = ms;
+        for (int k = 0; k < 8; k++) {
+            g.stats.kernel_ms[k] = 0.0f;
+            if (g.profiling && g.ev_used[k] && hipEventElapsedTime(&ms, g.ev[EV_K0 + 2 * k], g.ev[EV_K0 + 2 * k + 1]) == hipSuccess)
+                g.stats.kernel_ms[k] = ms;
+        }
+        if (g.pending_is_rt) {
+            unsigned long long hits = 0;
+            HIP_TRY(hipMemcpy(&hits, g.d_flags + 2, 8, hipMemcpyDeviceToHost));
+            g.stats.primary_rays = g.pending_primary;
+            g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
+            if (g.stats.mode_used == MIRT_RT_BRUTE)
+                g.stats.tests = (g.stats.primary_rays + g.stats.shadow_rays) * (uint64_t)g.n;
+        }
+        g.stats_pending = false;
+    }
+    *out = g.stats;
+    return MIRT_OK;
+}

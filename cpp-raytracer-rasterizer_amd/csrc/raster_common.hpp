@@ -1,0 +1,78 @@
+// raster_common.hpp -- parameter blocks and scratch buffers of the rasteriser kernels
+// (rasteriser/Source/rasteriser.cpp:461-482, 532-768).
+#pragma once
+
+#include "mirt_math.hpp"
+#include "../../include/mirt.h"
+
+namespace mirt {
+
+// Screen coordinates of a projected vertex beyond this are outside the contract: the reference itself
+// would size std::vectors from them (UB / bad_alloc).  Such triangles are skipped (oracle does the same).
+constexpr int RASTER_COORD_LIMIT = 1 << 20;
+
+// What VertexShader leaves per triangle, plus the row bookkeeping derived from it.
+struct TriSetup {
+    int x[3], y[3];          // Pixel::x, Pixel::y of the three projected vertices (rasteriser.cpp:544-545)
+    float zinv[3];           // Pixel::zinv (:541)
+    float p[3][3];           // Pixel::pos3d (:538)
+    int minY, maxY;          // ComputePolygonRows :679-680
+    int r0;                  // first row of this triangle inside the band [y0, y1)
+    int rows;                // rows inside the band (0 when culled / outside / out of contract)
+};
+
+// One edge's sample at one row, as Interpolate emits it (rasteriser.cpp:624-636): 5 fields per slot.
+// Slots of a row are stored field-major: slot[(row*3 + edge)*5 + field], field = {x, zinv, p.x, p.y, p.z}.
+constexpr int SLOT_FIELDS = 5;
+
+// The span DrawLineSDL/Bresenham walk for one (triangle,row) (rasteriser.cpp:592-612, 639-672).
+struct Span {
+    int ax, dx;              // a.x and b.x - a.x; pixels drawn are x = ax+1 .. ax+dx
+    float azinv, zstep;      // a.zinv, (b.zinv - a.zinv)/float(dx)          (:648)
+    float ap[3], pstep[3];   // a.pos3d, (b.pos3d - a.pos3d)/float(dx)       (:649)
+    int tri, y;
+};
+static_assert(sizeof(Span) == 48, "span record must be 48 bytes");
+
+struct RasterScratch {
+    TriSetup *setup = nullptr;       // n
+    uint32_t *row_base = nullptr;    // n + 1 (exclusive scan of TriSetup::rows), then block sums
+    uint32_t *block_sums = nullptr;
+    float *slots = nullptr;          // cap_rows * 3 * SLOT_FIELDS
+    Span *spans = nullptr;           // cap_rows
+    unsigned long long *keys = nullptr;   // band pixels
+    uint32_t *counters = nullptr;    // [0] total rows, [1] overflow flag
+    int cap_tris = 0;
+    size_t cap_rows = 0;
+    size_t cap_px = 0;
+    // sizing cache: the total row count of the previous frame with the same inputs
+    uint64_t sizing_key = 0;
+    bool sizing_valid = false;
+};
+
+struct RasterFrame {
+    const float *tris15;
+    const uint8_t *culled;
+    int n;
+    float cam[3];
+    float rot[9];
+    float invrot[9];
+    float focal;
+    int W, H;
+    int nlights;
+    float lpos[MIRT_MAX_LIGHTS][3];
+    float lcol[MIRT_MAX_LIGHTS][3];
+    float indirect[3];
+    int y0, y1, row_origin;
+    uint32_t *xrgb;
+    int pitch_words;
+    float *rgb;
+    float *zinv;
+    int32_t *index;
+    RasterScratch scratch;
+};
+
+int raster_scratch_ensure(RasterScratch &s, int n, int W, int band_rows);
+void raster_scratch_free(RasterScratch &s);
+
+}  // namespace mirt

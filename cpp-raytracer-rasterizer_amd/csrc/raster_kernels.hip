@@ -1,0 +1,378 @@
+// raster_kernels.hip -- hand-written gfx950 kernels for the rasteriser's Draw() loop
+// (rasteriser/Source/rasteriser.cpp: Draw :461-482, DrawPolygon :755-768, VertexShader :532-546,
+//  ComputePolygonRows :674-735 + Interpolate :615-637, DrawRows :738-753, DrawLineSDL :592-612,
+//  Bresenham :639-672, PixelShader :549-589, CalculateDOF :484-529, clear in Update :183-192).
+//
+// Pipeline per frame (all on one stream, no host round trip once the row count is known):
+//   k_raster_vertex   one thread per triangle: VertexShader x3, row range, rows inside the band
+//   k_scan_*          exclusive scan of rows-per-triangle -> row_base (where each triangle's rows live)
+//   k_raster_edges    one thread per (triangle, edge, field): Interpolate's SEQUENTIAL float accumulation,
+//                     bit for bit (a + k*step would round differently), written into per-row slots
+//   k_raster_spans    one thread per (triangle,row): strict-min / strict-max x over the <=3 edge samples
+//                     -> the span (a.x, b.x] and its zinv / pos3d steps
+//   k_raster_frag     one wave per span: zinv = a.zinv + zstep*float(i) per fragment and an atomic z-compare:
+//                     atomicMax on the u64 key  zinv_bits<<32 | (0xFFFFFFFF - tri)  (zinv > 0 orders as
+//                     unsigned bits; the reference's strict `>` with in-order triangles = max zinv, lowest
+//                     index among exact ties) -- race-free and deterministic, unlike the reference's OpenMP loop
+//   k_raster_resolve  one thread per pixel: decode the winner, rebuild its pos3d, PixelShader, and write the
+//                     XRGB word (+ optional float colour / depth / index planes) with coalesced stores
+#include "raster_common.hpp"
+
+#include <limits.h>
+
+namespace mirt {
+
+// ---- VertexShader (rasteriser.cpp:532-546) ------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raster_vertex(const RasterFrame f)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= f.n) return;
+    const float *tri = f.tris15 + (size_t)15 * t;
+    const v3 cam = ld3(f.cam);
+    TriSetup s;
+    bool ok = f.culled[t] == 0;                                        // Draw() :470
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const v3 pos = vec_mul_mat3(sub3(ld3(tri + 3 * k), cam), f.rot);   // (v - cameraPos) * cameraRot
+        const v3 p3 = div3s(pos, pos.z);                                    // pos / pos.z
+        const float zi = 1.0f / pos.z;
+        s.p[k][0] = p3.x; s.p[k][1] = p3.y; s.p[k][2] = p3.z;
+        s.zinv[k] = zi;
+        s.x[k] = f2i_x86((float)f2i_x86(f.focal * (pos.x * zi)) + ((float)f.W / 2.0f));
+        s.y[k] = f2i_x86((float)f2i_x86(f.focal * (pos.y * zi)) + ((float)f.H / 2.0f));
+        if (s.x[k] <= -RASTER_COORD_LIMIT || s.x[k] >= RASTER_COORD_LIMIT ||
+            s.y[k] <= -RASTER_COORD_LIMIT || s.y[k] >= RASTER_COORD_LIMIT) ok = false;
+    }
+    s.maxY = max(max(s.y[0], s.y[1]), s.y[2]);
+    s.minY = min(min(s.y[0], s.y[1]), s.y[2]);
+    const int lo = max(s.minY, f.y0), hi = min(s.maxY, f.y1 - 1);
+    s.r0 = lo;
+    s.rows = (ok && hi >= lo) ? hi - lo + 1 : 0;
+    f.scratch.setup[t] = s;
+    f.scratch.row_base[t] = (uint32_t)s.rows;     // scanned in place by k_scan_*
+}
+
+// ---- exclusive scan of row counts (3 passes, 1024 items per block) -----------------------------------
+constexpr int SCAN_ITEMS = 1024;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256x4(uint32_t v[4], uint32_t *total)
+{
+    __shared__ uint32_t s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { if (w < wave) wave_off += s_wave[w]; all += s_wave[w]; }
+    *total = all;
+    return wave_off + incl - mine;
+}
+
+__global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t *__restrict__ in, int n, uint32_t *__restrict__ sums)
+{
+    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? in[base + i] : 0u;
+    uint32_t total;
+    (void)block_exclusive_scan_256x4(v, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the block sums in place; total -> counters[0]
+__global__ __launch_bounds__(256) void k_scan_sums(uint32_t *__restrict__ sums, int nblocks, uint32_t *__restrict__ counters)
+{
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += SCAN_ITEMS) {
+        const int i0 = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = (i0 + i < nblocks) ? sums[i0 + i] : 0u;
+        uint32_t total;
+        uint32_t off = block_exclusive_scan_256x4(v, &total) + s_carry;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { if (i0 + i < nblocks) sums[i0 + i] = off; off += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counters[0] = s_carry; counters[1] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(uint32_t *__restrict__ data, int n, const uint32_t *__restrict__ sums,
+                                                    const uint32_t *__restrict__ counters)
+{
+    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? data[base + i] : 0u;
+    uint32_t total;
+    uint32_t off = block_exclusive_scan_256x4(v, &total) + sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { if (base + i < n) data[base + i] = off; off += v[i]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) data[n] = counters[0];
+}
+
+// ---- Interpolate along the three edges (rasteriser.cpp:615-637, called from :706-715) -----------------
+// One thread per (triangle, edge, field).  `current += step` is a dependent float chain, so each chain is a
+// thread of its own; 15 chains per triangle run side by side.  field: 0 = x, 1 = zinv, 2..4 = pos3d.
+__global__ __launch_bounds__(256) void k_raster_edges(const RasterFrame f)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = id / 15;
+    if (t >= f.n) return;
+    const TriSetup &s = f.scratch.setup[t];
+    const int rows = s.rows;
+    if (rows == 0) return;
+    const int e = (id % 15) / 5, fld = id % 5;
+    const int i = e, j = (e + 1) % 3;
+    const int ya = s.y[i], yb = s.y[j];
+    const int N = abs(ya - yb) + 1;                                  // :713
+    const float div = (float)max(N - 1, 1);                          // :622
+    float cur, step;
+    if (fld == 0) { cur = (float)s.x[i]; step = (float)(s.x[j] - s.x[i]) / div; }
+    else if (fld == 1) { cur = s.zinv[i]; step = (s.zinv[j] - s.zinv[i]) / div; }
+    else { cur = s.p[i][fld - 2]; step = (s.p[j][fld - 2] - s.p[i][fld - 2]) / div; }
+    const int dir = (yb > ya) - (yb < ya);
+    const int r0 = s.r0, r1 = s.r0 + rows;                           // band rows [r0, r1)
+    const size_t base = f.scratch.row_base[t];
+    if (base + (size_t)rows > f.scratch.cap_rows) { if (fld == 0 && e == 0) atomicExch(&f.scratch.counters[1], 1u); return; }
+    float *slots = f.scratch.slots;
+    int y = ya;
+    for (int k = 0; k < N; k++) {
+        if (y >= r0 && y < r1) {
+            float *slot = slots + ((base + (size_t)(y - r0)) * 3 + e) * SLOT_FIELDS;
+            slot[fld] = (fld == 0) ? __int_as_float(f2i_x86(cur)) : cur;      // result[i].x = current.x (:628)
+        }
+        if ((dir > 0 && y >= r1 - 1) || (dir < 0 && y <= r0)) break;  // later samples fall outside the band
+        cur += step;                                                  // :632-635, sequential on purpose
+        y += dir;
+    }
+}
+
+__device__ __forceinline__ int find_tri(const uint32_t *row_base, int n, uint32_t r)
+{
+    int lo = 0, hi = n;                      // row_base[lo] <= r < row_base[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (row_base[mid] <= r) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- left/right per row (rasteriser.cpp:716-733) and the span constants (:646-649) --------------------
+__global__ __launch_bounds__(256) void k_raster_spans(const RasterFrame f)
+{
+    const uint32_t R = min(f.scratch.counters[0], (uint32_t)f.scratch.cap_rows);
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const int t = find_tri(f.scratch.row_base, f.n, r);
+        const TriSetup &s = f.scratch.setup[t];
+        const int y = s.r0 + (int)(r - f.scratch.row_base[t]);
+        int lx = INT_MAX, rx = -INT_MAX;
+        float lz = 0.0f, rz = 0.0f;
+        v3 lp = V3(0, 0, 0), rp = V3(0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int ya = s.y[e], yb = s.y[(e + 1) % 3];
+            if (y < min(ya, yb) || y > max(ya, yb)) continue;       // this edge has no sample on this row
+            const float *slot = f.scratch.slots + ((size_t)r * 3 + e) * SLOT_FIELDS;
+            const int x = __float_as_int(slot[0]);
+            if (x < lx) { lx = x; lz = slot[1]; lp = V3(slot[2], slot[3], slot[4]); }   // strict <, first edge wins ties
+            if (x > rx) { rx = x; rz = slot[1]; rp = V3(slot[2], slot[3], slot[4]); }   // strict >
+        }
+        Span sp;
+        sp.tri = t; sp.y = y;
+        sp.ax = lx;
+        const long long d = (long long)rx - (long long)lx;
+        sp.dx = (d > 0 && d < (1ll << 22)) ? (int)d : 0;
+        const float fdx = (float)sp.dx;
+        sp.azinv = lz;
+        sp.zstep = (rz - lz) / fdx;                                   // :648 (unused when dx == 0)
+        const v3 ps = div3s(sub3(rp, lp), fdx);                       // :649
+        sp.ap[0] = lp.x; sp.ap[1] = lp.y; sp.ap[2] = lp.z;
+        sp.pstep[0] = ps.x; sp.pstep[1] = ps.y; sp.pstep[2] = ps.z;
+        f.scratch.spans[r] = sp;
+    }
+}
+
+// ---- fragments with an atomic z-compare (rasteriser.cpp:603-610, 657-669) -----------------------------
+__global__ __launch_bounds__(256) void k_raster_frag(const RasterFrame f)
+{
+    const uint32_t R = min(f.scratch.counters[0], (uint32_t)f.scratch.cap_rows);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t r = wave_id; r < R; r += nwaves) {
+        const Span &sp = f.scratch.spans[r];
+        const int dx = sp.dx;
+        if (dx <= 0) continue;
+        const int ax = sp.ax, y = sp.y;
+        // fragments are x = ax+1+i, i in [0,dx); those with x outside [0,W) are never produced (:663, E-2)
+        const int i0 = max(0, -ax - 1), i1 = min(dx, f.W - ax - 1);
+        const float azinv = sp.azinv, zstep = sp.zstep;
+        const unsigned long long low = 0xFFFFFFFFull - (unsigned long long)(uint32_t)sp.tri;
+        unsigned long long *row = f.scratch.keys + (size_t)(y - f.y0) * f.W;
+        for (int i = i0 + lane; i < i1; i += 64) {
+            const float zinv = azinv + zstep * (float)i;              // :667
+            if (zinv > 0.0f)                                          // depthBuffer starts at 0, strict > (:606)
+                atomicMax(row + (ax + 1 + i), ((unsigned long long)__float_as_uint(zinv) << 32) | low);
+        }
+    }
+}
+
+// ---- PixelShader (rasteriser.cpp:549-589) on the winner + CalculateDOF's PutPixelSDL (:491-519) ------
+__global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = f.y0 + blockIdx.y;
+    if (x >= f.W) return;
+    const unsigned long long key = f.scratch.keys[(size_t)(y - f.y0) * f.W + x];
+    v3 colour = V3(0.0f, 0.0f, 0.0f);            // Update() cleared pixelColours (:189)
+    float zinv = 0.0f;                           // and depthBuffer (:188)
+    int tri = -1;
+    if (key != 0ull) {
+        tri = (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+        zinv = __uint_as_float((uint32_t)(key >> 32));
+        const TriSetup &s = f.scratch.setup[tri];
+        const Span &sp = f.scratch.spans[f.scratch.row_base[tri] + (uint32_t)(y - s.r0)];
+        const float fi = (float)(x - sp.ax - 1);
+        const v3 p3 = add3(ld3(sp.ap), scale3(ld3(sp.pstep), fi));   // a.pos3d + pos3d*float(i) (:668)
+        const float *t15 = f.tris15 + (size_t)15 * tri;
+        const v3 normal = ld3(t15 + 9), color = ld3(t15 + 12);
+        v3 P = div3s(p3, zinv);                                       // pPos3d /= p.zinv (:557)
+        P = vec_mul_mat3(P, f.invrot);                                // * glm::inverse(cameraRot) (:559)
+        P = add3(P, ld3(f.cam));                                      // += cameraPos (:560)
+        v3 result = V3(0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < f.nlights; k++) {
+            const v3 L = ld3(f.lpos[k]);
+            const float r = distance3(P, L);                          // :574
+            const float A = sphere_area(r);                           // :575
+            const v3 rDir = normalize3(sub3(L, P));                   // :577
+            const v3 B = div3s(ld3(f.lcol[k]), A);                    // :579
+            const float d = dot3(rDir, normal);                       // normal NOT re-normalised here (:578)
+            const float m = (d < 0.0f) ? 0.0f : d;                    // std::max (:581)
+            result = add3(result, scale3(B, m));
+        }
+        // currentReflectance(1,1,1) * (result + indirectLightPowerPerArea) * color (:587)
+        colour = mul3(mul3(V3(1.0f, 1.0f, 1.0f), add3(result, ld3(f.indirect))), color);
+    }
+    const size_t px = (size_t)y * f.W + x;
+    if (f.rgb) st3(f.rgb + 3 * px, colour);
+    if (f.zinv) f.zinv[px] = zinv;
+    if (f.index) f.index[px] = tri;
+    // Update() paints every pixel black (:190); CalculateDOF then draws the interior only (:491-493)
+    const bool interior = x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1;
+    f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = interior ? pack_xrgb(colour) : 0u;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+
+void raster_scratch_free(RasterScratch &s)
+{
+    for (void *p : { (void *)s.setup, (void *)s.row_base, (void *)s.block_sums, (void *)s.slots, (void *)s.spans,
+                     (void *)s.keys, (void *)s.counters })
+        if (p) (void)hipFree(p);
+    s = RasterScratch();
+}
+
+static int grow(void **p, size_t bytes)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    return hipMalloc(p, bytes) == hipSuccess ? MIRT_OK : MIRT_ERR_OUT_OF_MEMORY;
+}
+
+static int ensure_rows(RasterScratch &s, size_t rows)
+{
+    if (rows <= s.cap_rows) return MIRT_OK;
+    size_t cap = rows + rows / 8 + 1024;
+    if (grow((void **)&s.slots, cap * 3 * SLOT_FIELDS * sizeof(float))) { s.cap_rows = 0; return MIRT_ERR_OUT_OF_MEMORY; }
+    if (grow((void **)&s.spans, cap * sizeof(Span))) { s.cap_rows = 0; return MIRT_ERR_OUT_OF_MEMORY; }
+    s.cap_rows = cap;
+    return MIRT_OK;
+}
+
+int raster_scratch_ensure(RasterScratch &s, int n, int W, int band_rows)
+{
+    if (!s.counters && grow((void **)&s.counters, 16)) return MIRT_ERR_OUT_OF_MEMORY;
+    if (n > s.cap_tris) {
+        if (grow((void **)&s.setup, (size_t)n * sizeof(TriSetup))) return MIRT_ERR_OUT_OF_MEMORY;
+        if (grow((void **)&s.row_base, ((size_t)n + 1) * sizeof(uint32_t))) return MIRT_ERR_OUT_OF_MEMORY;
+        if (grow((void **)&s.block_sums, ((size_t)n / SCAN_ITEMS + 2) * sizeof(uint32_t))) return MIRT_ERR_OUT_OF_MEMORY;
+        s.cap_tris = n;
+        s.sizing_valid = false;
+    }
+    const size_t px = (size_t)W * band_rows;
+    if (px > s.cap_px) {
+        if (grow((void **)&s.keys, px * sizeof(unsigned long long))) { s.cap_px = 0; return MIRT_ERR_OUT_OF_MEMORY; }
+        s.cap_px = px;
+    }
+    return ensure_rows(s, 4096);
+}
+
+static uint64_t frame_key(const RasterFrame &f, uint64_t scene_version)
+{
+    uint64_t h = 0xcbf29ce484222325ull ^ scene_version;
+    auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; } };
+    mix(f.cam, sizeof f.cam); mix(f.rot, sizeof f.rot); mix(&f.focal, 4); mix(&f.W, 4); mix(&f.H, 4);
+    mix(&f.y0, 4); mix(&f.y1, 4); mix(&f.n, 4);
+    return h | 1ull;
+}
+
+// Enqueues the whole rasteriser frame on `stream`.  ev (nullable) = the library's per-kernel event pairs,
+// indexed 2*MIRT_K_*.  Returns 0 or a negative mirt_status.
+int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev)
+{
+    auto begin = [&](int k) { if (ev) (void)hipEventRecord(ev[2 * k], stream); };
+    auto end = [&](int k) { if (ev) (void)hipEventRecord(ev[2 * k + 1], stream); };
+    const int band_rows = f.y1 - f.y0;
+    const int nblk = (f.n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+
+    begin(MIRT_K_CLEAR);
+    if (hipMemsetAsync(s.keys, 0, (size_t)f.W * band_rows * sizeof(unsigned long long), stream) != hipSuccess) return MIRT_ERR_HIP;
+    end(MIRT_K_CLEAR);
+
+    begin(MIRT_K_RASTER_SETUP);
+    f.scratch = s;
+    hipLaunchKernelGGL(k_raster_vertex, dim3((f.n + 255) / 256), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, stream, s.row_base, f.n, s.block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, s.block_sums, nblk, s.counters);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(256), 0, stream, s.row_base, f.n, s.block_sums, s.counters);
+
+    // The slot / span tables are sized from the total row count.  It is read back (one 4-byte copy + sync)
+    // only when the frame's geometry inputs changed since the last call; otherwise last frame's count holds.
+    const uint64_t key = frame_key(f, scene_version);
+    if (!s.sizing_valid || s.sizing_key != key) {
+        uint32_t total = 0;
+        if (hipMemcpyAsync(&total, s.counters, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MIRT_ERR_HIP;
+        if (hipStreamSynchronize(stream) != hipSuccess) return MIRT_ERR_HIP;
+        if (ensure_rows(s, total)) return MIRT_ERR_OUT_OF_MEMORY;
+        s.sizing_key = key;
+        s.sizing_valid = true;
+        f.scratch = s;
+    }
+    hipLaunchKernelGGL(k_raster_edges, dim3(((size_t)f.n * 15 + 255) / 256), dim3(256), 0, stream, f);
+    const int span_blocks = (int)min((size_t)4096, (s.cap_rows + 255) / 256);
+    hipLaunchKernelGGL(k_raster_spans, dim3(span_blocks), dim3(256), 0, stream, f);
+    end(MIRT_K_RASTER_SETUP);
+
+    begin(MIRT_K_RASTER_FRAG);
+    const int frag_blocks = (int)min((size_t)8192, (s.cap_rows + 3) / 4);
+    hipLaunchKernelGGL(k_raster_frag, dim3(frag_blocks), dim3(256), 0, stream, f);
+    end(MIRT_K_RASTER_FRAG);
+
+    begin(MIRT_K_RASTER_RESOLVE);
+    hipLaunchKernelGGL(k_raster_resolve, dim3((f.W + 255) / 256, band_rows), dim3(256), 0, stream, f);
+    end(MIRT_K_RASTER_RESOLVE);
+    return hipGetLastError() == hipSuccess ? MIRT_OK : MIRT_ERR_HIP;
+}
+
+}  // namespace mirt

@@ -1,0 +1,139 @@
+// rt_common.hpp -- shared device code of the ray-trace kernels: the origin table, the conservative
+// pre-reject filter and the exact accept path of ClosestIntersection (raytracer.cpp:202-257).
+#pragma once
+
+#include "mirt_math.hpp"
+#include "../../include/mirt.h"
+
+namespace mirt {
+
+// ---- origin table ------------------------------------------------------------------------------------
+// For a fixed ray origin S (the camera, or one light) everything in ClosestIntersection that does not
+// depend on the ray direction is hoisted into 12 floats per triangle (same operands,
+// same operations => same bits as recomputing them per ray):
+//   row0 = { e1e2.x, e1e2.y, e1e2.z, e1e2b }    e1e2 = cross(e1,e2), e1e2b = dot(e1e2, b)   (:225,:231)
+//   row1 = { be2.x,  be2.y,  be2.z,  0 }        be2  = cross(b, e2), b = S - v0              (:218,:226)
+//   row2 = { e1b.x,  e1b.y,  e1b.z,  0 }        e1b  = cross(e1, b)                          (:227)
+// 48 bytes per triangle, read as three 16-byte LDS broadcasts per test.
+struct OriginRow { float4 r0, r1, r2; };
+static_assert(sizeof(OriginRow) == 48, "origin row must be 48 bytes");
+
+// Rows of the origin table staged into LDS per workgroup pass: 48 KiB at most, 3 workgroups per CU.
+constexpr int RT_CHUNK_ROWS = 1024;
+
+// Largest |value| an origin-table entry, a vertex or a light coordinate may have for the pre-reject
+// filter's proof to hold (keeps every dot product finite); scenes beyond it take the exact-only path.
+#define MIRT_SAFE_MAG 1.0e18f
+
+MIRT_HD OriginRow make_origin_row(const float *t15, v3 S)
+{
+    v3 v0 = ld3(t15), v1 = ld3(t15 + 3), v2 = ld3(t15 + 6);
+    v3 e1 = sub3(v1, v0), e2 = sub3(v2, v0), b = sub3(S, v0);
+    v3 e1e2 = cross3(e1, e2), be2 = cross3(b, e2), e1b = cross3(e1, b);
+    float e1e2b = e1e2.x * b.x + e1e2.y * b.y + e1e2.z * b.z;
+    OriginRow r;
+    r.r0 = make_float4(e1e2.x, e1e2.y, e1e2.z, e1e2b);
+    r.r1 = make_float4(be2.x, be2.y, be2.z, 0.0f);
+    r.r2 = make_float4(e1b.x, e1b.y, e1b.z, 0.0f);
+    return r;
+}
+
+MIRT_HD bool origin_row_safe(const OriginRow &r)
+{
+    float m = fmaxf(fmaxf(fmaxf(fabsf(r.r0.x), fabsf(r.r0.y)), fmaxf(fabsf(r.r0.z), fabsf(r.r0.w))),
+                    fmaxf(fmaxf(fmaxf(fabsf(r.r1.x), fabsf(r.r1.y)), fabsf(r.r1.z)),
+                          fmaxf(fmaxf(fabsf(r.r2.x), fabsf(r.r2.y)), fabsf(r.r2.z))));
+    return m < MIRT_SAFE_MAG;   // false for NaN too
+}
+
+// ---- the per-test arithmetic ---------------------------------------------------------------------------
+
+struct TestDots { float den, pu, qv; };
+
+// e1e2d, be2d, e1bd (raytracer.cpp:232-234) for negD = nd: three hand-written dot products, products
+// first, summed left to right.  Exact reference order; no FMA (the TU is built with -ffp-contract=off).
+__device__ __forceinline__ TestDots test_dots(const float4 &r0, const float4 &r1, const float4 &r2, v3 nd)
+{
+    TestDots d;
+    d.den = r0.x * nd.x + r0.y * nd.y + r0.z * nd.z;
+    d.pu = r1.x * nd.x + r1.y * nd.y + r1.z * nd.z;
+    d.qv = r2.x * nd.x + r2.y * nd.y + r2.z * nd.z;
+    return d;
+}
+
+// Conservative pre-reject.  Returns false ONLY when the reference's test
+//     u + v <= 1 && u >= 0 && v >= 0 && t >= 0,   u = be2d/e1e2d, v = e1bd/e1e2d   (raytracer.cpp:237-239)
+// is certain to fail; true means "run the exact path".  With s = sign(e1e2d):  a = s*be2d, b = s*e1bd,
+// D = |e1e2d|.  Proof sketch (DESIGN.md section 4.2 has the full argument, valid while every operand is
+// finite and below MIRT_SAFE_MAG):
+//   u >= 0 (incl. -0 from underflow) needs a > -2^-22, since |e1e2d| < 2^128 keeps |a|/D above 2^-150;
+//   likewise v >= 0 needs b > -2^-22;
+//   u + v <= 1 after rounding needs a + b <= D*(1 + 2^-22), so fma(D, 1 + 2^-20, -(a+b)) >= 0.
+// Anything the filter lets through is decided by the exact divisions, so a loose filter costs time only.
+__device__ __forceinline__ bool maybe_hit(const TestDots &d)
+{
+    const uint32_t sgn = __float_as_uint(d.den) & 0x80000000u;
+    const float a = __uint_as_float(__float_as_uint(d.pu) ^ sgn);
+    const float b = __uint_as_float(__float_as_uint(d.qv) ^ sgn);
+    const float slack = __builtin_fmaf(fabsf(d.den), 1.00000095367431640625f, -(a + b));
+    return fminf(fminf(a, b), slack) >= -2.384185791015625e-07f;
+}
+
+// The accept test and hit point exactly as the reference computes them (raytracer.cpp:237-242).
+// Returns true when the triangle is accepted; *dist = glm::distance(start, pos).
+__device__ __forceinline__ bool exact_hit(const TestDots &d, float e1e2b, const float *t15, v3 start,
+                                          v3 *pos, float *dist)
+{
+    const float t = e1e2b / d.den, u = d.pu / d.den, v = d.qv / d.den;
+    if (u + v <= 1.0f && u >= 0.0f && v >= 0.0f && t >= 0.0f) {
+        const v3 v0 = ld3(t15), v1 = ld3(t15 + 3), v2 = ld3(t15 + 6);
+        const v3 e1 = sub3(v1, v0), e2 = sub3(v2, v0);
+        const v3 p = add3(add3(v0, scale3(e1, u)), scale3(e2, v));
+        *pos = p;
+        *dist = distance3(start, p);
+        return true;
+    }
+    return false;
+}
+
+// ---- kernel parameters ---------------------------------------------------------------------------------
+
+struct RtFrame {
+    const float *tris15;        // n x 15, reference AoS order
+    int n;
+    const OriginRow *cam_tab;   // n rows for the camera origin
+    const OriginRow *light_tab; // nlights x n rows
+    const uint32_t *unsafe;     // != 0: some operand is outside the filter's proven range -> exact-only path
+    float cam[3];
+    float rot[9];
+    float focal;
+    int W, H;
+    int nlights;
+    float lpos[MIRT_MAX_LIGHTS][3];
+    float lcol[MIRT_MAX_LIGHTS][3];   // lights[k].color * lights[k].intensity (raytracer.cpp:282)
+    float indirect[3];
+    int y0, y1, row_origin;
+    uint32_t *xrgb;
+    int pitch_words;
+    float *rgb;                 // nullable, stride W
+    int32_t *index;             // nullable, stride W
+    unsigned long long *hit_count;
+};
+
+// Per-light shading term D of DirectLight (raytracer.cpp:294-304) before the shadow test.
+__device__ __forceinline__ v3 light_term(const RtFrame &f, int k, v3 hit, v3 nDir, v3 *rDir, float *r)
+{
+    const v3 L = ld3(f.lpos[k]);
+    const float rr = distance3(hit, L);
+    const float A = sphere_area(rr);
+    const v3 P = div3s(ld3(f.lcol[k]), 1.0f);          // lightColor /= (float)samples, samples == 1
+    const v3 rd = normalize3(sub3(L, hit));
+    const v3 B = div3s(P, A);
+    const float d = dot3(rd, nDir);
+    const float m = (d < 0.0f) ? 0.0f : d;             // std::max(d, 0.0f)
+    *rDir = rd;
+    *r = rr;
+    return scale3(B, m);
+}
+
+}  // namespace mirt

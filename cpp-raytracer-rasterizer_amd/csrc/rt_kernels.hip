@@ -1,0 +1,201 @@
+// rt_kernels.hip -- hand-written gfx950 kernels for the ray tracer's Draw() loop
+// (raytracer/Source/raytracer.cpp:547-606 -> ClosestIntersection :202-257 -> DirectLight :265-327 ->
+//  CalculateDOF/PutPixelSDL :608-656, SDLauxiliary.h:70-81).
+//
+// One thread owns one pixel (P pixels when P > 1), the triangle list is staged into LDS once per workgroup
+// chunk and every lane walks it with wave-uniform (broadcast) LDS reads; results leave through coalesced
+// 32-bit framebuffer stores.  No MFMA: this is not a contraction.  Built with -ffp-contract=off.
+#include "rt_common.hpp"
+
+#include <float.h>
+
+namespace mirt {
+
+// ---- k_prep_origin: origin tables for the camera and every light --------------------------------------
+// grid.y = 1 + nlights (0 = camera), one thread per triangle.  Also raises *unsafe when an entry is outside
+// the pre-reject filter's proven range (then the trace kernels skip the filter).
+__global__ __launch_bounds__(256) void k_prep_origin(const float *__restrict__ tris15, int n,
+                                                     const float *__restrict__ origins /* (1+nl) x 3 */,
+                                                     OriginRow *__restrict__ cam_tab,
+                                                     OriginRow *__restrict__ light_tab,
+                                                     uint32_t *__restrict__ unsafe)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.y;
+    if (i >= n) return;
+    const v3 S = ld3(origins + 3 * o);
+    const OriginRow r = make_origin_row(tris15 + (size_t)15 * i, S);
+    OriginRow *dst = (o == 0) ? cam_tab : light_tab + (size_t)(o - 1) * n;
+    dst[i] = r;
+    if (!origin_row_safe(r)) atomicOr(unsafe, 1u);
+}
+
+// ---- k_rt_brute: fused primary + shadow + shade + resolve, every ray tests every triangle ------------
+//
+// Workgroup = 256 threads = 4 wave64; wave w of block (bx, by) owns row y0 + 4*by + w, pixels
+// x = bx*64*P + p*64 + lane, so each framebuffer store instruction writes 64 consecutive words (256 B).
+// The origin table is staged through LDS in chunks of CHUNK rows (48 B each); all 64 lanes read the same
+// row => three conflict-free ds_read_b128 broadcasts per triangle, reused for the lane's P rays.
+constexpr int RT_CHUNK = RT_CHUNK_ROWS;
+
+template <int P, bool FILTER>
+__device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = f.y0 + (int)blockIdx.y * 4 + wave;
+    const bool row_ok = y < f.y1;
+    const v3 cam = ld3(f.cam);
+    const float halfW = (float)f.W / 2.0f, halfH = (float)f.H / 2.0f;
+
+    int xs[P];
+    bool ok[P];
+    v3 nd[P], pos[P];
+    float best_d[P];
+    int best_i[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        xs[p] = ((int)blockIdx.x * P + p) * 64 + lane;
+        ok[p] = row_ok && xs[p] < f.W;
+        // d = (x - W/2, y - H/2, focalLength); dir = cameraRot * d   (raytracer.cpp:579-580)
+        const v3 d = V3((float)xs[p] - halfW, (float)y - halfH, f.focal);
+        nd[p] = neg3(mat3_mul_vec(f.rot, d));            // negD = -dir (:229)
+        best_d[p] = FLT_MAX;                              // Update() reset (:335-339)
+        best_i[p] = -1;
+        pos[p] = V3(0.0f, 0.0f, 0.0f);
+    }
+
+    // ---------------- primary rays: closest hit, ties -> later index (:243) ----------------
+    for (int base = 0; base < f.n; base += RT_CHUNK) {
+        const int cnt = min(RT_CHUNK, f.n - base);
+        __syncthreads();
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + base);
+            for (int k = threadIdx.x; k < cnt * 3; k += 256) s_tab[k] = src[k];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < cnt; j++) {
+            const float4 r0 = s_tab[3 * j], r1 = s_tab[3 * j + 1], r2 = s_tab[3 * j + 2];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const TestDots d = test_dots(r0, r1, r2, nd[p]);
+                if (!FILTER || maybe_hit(d)) {
+                    v3 hp;
+                    float dist;
+                    if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), cam, &hp, &dist)) {
+                        if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = base + j; pos[p] = hp; }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- DirectLight: one shadow ray per light per hit pixel ----------------
+    v3 result[P], result2[P], nDir[P], tcol[P];
+    bool hit[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        hit[p] = ok[p] && best_i[p] >= 0;
+        result[p] = result2[p] = V3(0.0f, 0.0f, 0.0f);
+        const float *t = f.tris15 + (size_t)15 * (best_i[p] >= 0 ? best_i[p] : 0);
+        nDir[p] = normalize3(ld3(t + 9));                 // glm::normalize(triangles[idx].normal) (:300)
+        tcol[p] = ld3(t + 12);
+    }
+    {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
+        if (lane == 0 && m) atomicAdd(f.hit_count, m);
+    }
+
+    for (int k = 0; k < f.nlights; k++) {
+        const v3 L = ld3(f.lpos[k]);
+        v3 D[P], rd[P];
+        float thr[P];
+        bool live[P];      // still needs shadow testing
+        bool any_live = false;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            float r;
+            D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
+            thr[p] = r * 0.99f;                            // j.distance < r*0.99f (:313)
+            live[p] = hit[p];
+            any_live |= live[p];
+        }
+        const OriginRow *tab = f.light_tab + (size_t)k * f.n;
+        // every wave of the block must take part in the staging barriers, so the chunk loop is
+        // unconditional; a wave with nothing left to test just skips the inner loop.
+        for (int base = 0; base < f.n; base += RT_CHUNK) {
+            const int cnt = min(RT_CHUNK, f.n - base);
+            __syncthreads();
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(tab + base);
+                for (int q = threadIdx.x; q < cnt * 3; q += 256) s_tab[q] = src[q];
+            }
+            __syncthreads();
+            if (!__any(any_live)) continue;
+#pragma unroll 2
+            for (int j = 0; j < cnt; j++) {
+                const float4 r0 = s_tab[3 * j], r1 = s_tab[3 * j + 1], r2 = s_tab[3 * j + 2];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    // shadow ray: start = light, dir = -rDir, so negD = rDir (:310, :229)
+                    const TestDots d = test_dots(r0, r1, r2, rd[p]);
+                    if (live[p] && (!FILTER || maybe_hit(d))) {
+                        v3 hp;
+                        float dist;
+                        if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), L, &hp, &dist)) {
+                            // min over accepted hits < thr  <=>  some accepted hit < thr (any-hit is exact)
+                            if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);
+                        }
+                    }
+                }
+            }
+            any_live = false;
+#pragma unroll
+            for (int p = 0; p < P; p++) any_live |= live[p];
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            result[p] = add3(result[p], D[p]);             // result += D   (:319)
+            result2[p] = add3(result2[p], result[p]);      // result2 += result, reference quirk (:322)
+        }
+    }
+
+    // ---------------- shade + resolve ----------------
+    const v3 N = ld3(f.indirect);
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        if (!ok[p]) continue;
+        v3 avg = V3(0.0f, 0.0f, 0.0f);
+        if (hit[p]) {
+            const v3 Dl = mul3(result2[p], tcol[p]);       // DirectLight returns result2 * color (:325-326)
+            const v3 T = add3(Dl, N);                      // (:584-586)
+            const v3 R = mul3(tcol[p], T);                 // (:587-588)
+            avg = add3(avg, R);                            // (:591)
+        }
+        avg = div3s(avg, 1.0f);                            // /= realSamples^2 (:599)
+        const int x = xs[p];
+        const size_t px = (size_t)y * f.W + x;
+        if (f.rgb) st3(f.rgb + 3 * px, avg);
+        if (f.index) f.index[px] = best_i[p];
+        // CalculateDOF draws interior pixels only (:618-620); the border keeps its old value
+        if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)
+            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_rt_brute(const RtFrame f)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
+    if (__builtin_amdgcn_readfirstlane(*f.unsafe) == 0u)
+        brute_body<P, true>(f, s_tab);
+    else
+        brute_body<P, false>(f, s_tab);
+}
+
+template __global__ void k_rt_brute<1>(const RtFrame);
+template __global__ void k_rt_brute<2>(const RtFrame);
+
+}  // namespace mirt

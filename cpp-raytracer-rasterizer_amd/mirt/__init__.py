@@ -1,0 +1,230 @@
+"""mirt -- thin ctypes binding of the C-ABI in include/mirt.h (libmirt.so, hand-written gfx950 kernels).
+
+This module is plumbing for tests and bench.py: it marshals numpy arrays (or device pointers of torch
+tensors) into the C entry points.  There is no Python/CPU implementation of the render path here and no
+fallback: if libmirt.so is missing or no MI355X is visible, the calls raise MirtError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmirt.so")
+
+MAX_LIGHTS = 32
+RT_AUTO, RT_BRUTE, RT_BINNED = 0, 1, 2
+KERNEL_NAMES = ("prep", "bin", "trace", "shade", "raster_setup", "raster_frag", "raster_resolve", "clear")
+
+# every symbol include/mirt.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = (
+    "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
+    "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
+    "mirt_scene_soup", "mirt_cull", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
+    "mirt_rasterise_device", "mirt_get_stats",
+)
+
+
+class MirtError(RuntimeError):
+    pass
+
+
+class View(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("rot", C.c_float * 9), ("focal", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("color", C.c_float * 3), ("intensity", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tests", C.c_uint64),
+                ("gpu_ms", C.c_float), ("kernel_ms", C.c_float * 8), ("mode_used", C.c_int32)]
+
+
+_vp = C.c_void_p
+_lib = None
+
+
+def load():
+    """Loads libmirt.so (raises MirtError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MirtError("libmirt.so not built: run `make -C cpp-raytracer-rasterizer_amd` (or __graft_entry__.build())")
+    lib = C.CDLL(LIB_PATH)
+    lib.mirt_last_error.restype = C.c_char_p
+    lib.mirt_stream.restype = _vp
+    lib.mirt_init.argtypes = [C.c_int]
+    lib.mirt_set_profiling.argtypes = [C.c_int]
+    lib.mirt_scene_upload.argtypes = [_vp, _vp, C.c_int]
+    lib.mirt_scene_set_culled.argtypes = [_vp, C.c_int]
+    lib.mirt_scene_cornell.argtypes = [_vp]
+    lib.mirt_scene_soup.argtypes = [C.c_uint32, C.c_int, C.c_float, _vp]
+    lib.mirt_cull.argtypes = [_vp, C.c_int, C.POINTER(View), C.c_int, _vp]
+    lib.mirt_raytrace.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
+    lib.mirt_raytrace_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         _vp, C.c_int, _vp, _vp]
+    lib.mirt_rasterise.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]
+    lib.mirt_rasterise_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+                                          _vp, C.c_int, _vp, _vp, _vp]
+    lib.mirt_get_stats.argtypes = [C.POINTER(Stats)]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MirtError("mirt error %d: %s" % (rc, load().mirt_last_error().decode()))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def make_view(pos, rot9, focal, W, H):
+    v = View()
+    v.pos[:] = [float(x) for x in pos]
+    v.rot[:] = [float(x) for x in np.asarray(rot9, np.float32).ravel()]
+    v.focal = float(focal)
+    v.width, v.height = int(W), int(H)
+    return v
+
+
+def make_lights(lights7):
+    """lights7: (k, 7) array {pos, color, intensity} -> (ctypes array or None, k)."""
+    l = np.ascontiguousarray(lights7, np.float32).reshape(-1, 7)
+    if len(l) == 0:
+        return None, 0
+    arr = (Light * len(l))()
+    for i, r in enumerate(l):
+        arr[i].pos[:] = r[0:3].tolist()
+        arr[i].color[:] = r[3:6].tolist()
+        arr[i].intensity = float(r[6])
+    return arr, len(l)
+
+
+def rot_from_yaw(yaw, m11):
+    """cameraRot as the reference's Update() builds it (raytracer.cpp:377-382 / rasteriser.cpp:378-383)."""
+    c, s = np.float32(np.cos(np.float32(yaw))), np.float32(np.sin(np.float32(yaw)))
+    r = np.zeros(9, np.float32)
+    r[4] = m11
+    r[0], r[2], r[6], r[8] = c, s, -s, c
+    return r
+
+
+# ---- lifetime ---------------------------------------------------------------------------------------
+
+def init(device=0):
+    _check(load().mirt_init(int(device)))
+
+
+def shutdown():
+    if _lib is not None:
+        _lib.mirt_shutdown()
+
+
+def set_profiling(on):
+    _check(load().mirt_set_profiling(1 if on else 0))
+
+
+def sync():
+    _check(load().mirt_sync())
+
+
+def stats():
+    s = Stats()
+    _check(load().mirt_get_stats(C.byref(s)))
+    return {"primary_rays": s.primary_rays, "shadow_rays": s.shadow_rays, "tests": s.tests, "gpu_ms": s.gpu_ms,
+            "kernel_ms": dict(zip(KERNEL_NAMES, list(s.kernel_ms))), "mode_used": s.mode_used}
+
+
+# ---- scene ------------------------------------------------------------------------------------------
+
+def scene_cornell():
+    t = np.zeros((30, 15), np.float32)
+    n = load().mirt_scene_cornell(_ptr(t))
+    if n != 30:
+        _check(n if n < 0 else -3)
+    return t
+
+
+def scene_soup(seed, n, s):
+    t = np.zeros((n, 15), np.float32)
+    rc = load().mirt_scene_soup(int(seed), int(n), float(s), _ptr(t))
+    if rc != n:
+        _check(rc if rc < 0 else -3)
+    return t
+
+
+def cull(tris, view, flags=3):
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 15)
+    c = np.zeros(len(tris), np.uint8)
+    _check(load().mirt_cull(_ptr(tris), len(tris), C.byref(view), int(flags), _ptr(c)))
+    return c
+
+
+def scene_upload(tris, culled=None):
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 15)
+    culled = None if culled is None else np.ascontiguousarray(culled, np.uint8)
+    _check(load().mirt_scene_upload(_ptr(tris), _ptr(culled), len(tris)))
+
+
+def scene_set_culled(culled):
+    culled = np.ascontiguousarray(culled, np.uint8)
+    _check(load().mirt_scene_set_culled(_ptr(culled), len(culled)))
+
+
+# ---- render (host buffers) --------------------------------------------------------------------------
+
+def raytrace(view, lights7, indirect=(0.2, 0.2, 0.2), mode=RT_AUTO, want_rgb=True, want_index=True, xrgb=None):
+    W, H = view.width, view.height
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32)
+    out = {
+        "xrgb": np.zeros((H, W), np.uint32) if xrgb is None else xrgb,
+        "rgb": np.zeros((H, W, 3), np.float32) if want_rgb else None,
+        "index": np.zeros((H, W), np.int32) if want_index else None,
+    }
+    _check(load().mirt_raytrace(C.byref(view), larr, nl, _ptr(ind), int(mode), _ptr(out["xrgb"]),
+                                out["xrgb"].strides[0], _ptr(out["rgb"]), _ptr(out["index"])))
+    out["stats"] = stats()
+    return out
+
+
+def rasterise(view, lights7, indirect=(0.2, 0.2, 0.2), want_rgb=True, want_zinv=True, want_index=True):
+    W, H = view.width, view.height
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32)
+    out = {
+        "xrgb": np.full((H, W), 0xDEADBEEF, np.uint32),
+        "rgb": np.zeros((H, W, 3), np.float32) if want_rgb else None,
+        "depth": np.zeros((H, W), np.float32) if want_zinv else None,
+        "index": np.zeros((H, W), np.int32) if want_index else None,
+    }
+    _check(load().mirt_rasterise(C.byref(view), larr, nl, _ptr(ind), _ptr(out["xrgb"]), out["xrgb"].strides[0],
+                                 _ptr(out["rgb"]), _ptr(out["depth"]), _ptr(out["index"])))
+    out["stats"] = stats()
+    return out
+
+
+# ---- render (device buffers: raw pointers, e.g. torch.Tensor.data_ptr()) -----------------------------
+
+def raytrace_device(view, lights7, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb=None, d_index=None):
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32)
+    _check(load().mirt_raytrace_device(C.byref(view), larr, nl, _ptr(ind), int(mode), int(y0), int(y1),
+                                       int(row_origin), d_xrgb, int(pitch_bytes), d_rgb, d_index))
+
+
+def rasterise_device(view, lights7, indirect, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb=None, d_zinv=None,
+                     d_index=None):
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32)
+    _check(load().mirt_rasterise_device(C.byref(view), larr, nl, _ptr(ind), int(y0), int(y1), int(row_origin),
+                                        d_xrgb, int(pitch_bytes), d_rgb, d_zinv, d_index))
+
+
+DEFAULT_LIGHT = np.array([[0.0, -0.5, -0.7, 1.0, 1.0, 1.0, 14.0]], np.float32)

@@ -1,0 +1,165 @@
+/*
+ * mirt.h -- C-ABI of the MI355X-native per-pixel render path ("mirt").
+ *
+ * This is the drop-in boundary for the two hot loops of ArchDD/CPP-Raytracer-Rasterizer.  The reference
+ * has no plugin / FFI layer: its hot path is the free function `void Draw()` reading globals and writing
+ * through `PutPixelSDL` (raytracer/Source/raytracer.cpp:104,547; rasteriser/Source/rasteriser.cpp:86,461;
+ * raytracer/Source/SDLauxiliary.h:29,70-81).  Each entry point below names the reference interface it
+ * replaces.  The host-side `Draw()` adapter that marshals the reference-shaped globals into these calls is
+ * cpp-raytracer-rasterizer_amd/host/mirt_draw.hpp; INTEGRATION.md shows the lines a maintainer adds.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns 0 on success or a negative
+ *     mirt_status, with a human-readable message available from mirt_last_error();
+ *   - the library never exits the process and never falls back to a CPU path: without a usable GPU
+ *     every compute entry point fails with MIRT_ERR_NO_DEVICE;
+ *   - the caller owns every host pointer for the duration of a call; the library owns all device memory;
+ *   - entry points are meant for one host thread (the SDL loop), are not re-entrant, and are synchronous
+ *     (the frame is complete on return) unless the name ends in `_device`/`_async`;
+ *   - a triangle is 15 floats {v0, v1, v2, normal, color} -- the field order of `class Triangle`
+ *     (raytracer/Source/TestModel.h:11-32; sizeof == 60); a light is 7 floats {position, color,
+ *     intensity} == `class Light` (TestModel.h:35-45; sizeof == 28); matrices are GLM column-major mat3;
+ *   - per-pixel planes are row-major with row stride == width (the reference indexes them with
+ *     SCREEN_HEIGHT, which is only correct for its square 500x500 frame -- SURVEY Appendix E-1).
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_API __attribute__((visibility("default")))
+#define MIRT_ABI_VERSION 1
+#define MIRT_MAX_LIGHTS 32            /* Light lights[32], raytracer.cpp:48 / rasteriser.cpp:50 */
+
+typedef enum mirt_status {
+    MIRT_OK = 0,
+    MIRT_ERR_NO_DEVICE = -1,          /* no HIP device / wrong architecture                     */
+    MIRT_ERR_NOT_INITIALISED = -2,    /* mirt_init not called                                    */
+    MIRT_ERR_INVALID_ARGUMENT = -3,
+    MIRT_ERR_NO_SCENE = -4,           /* render call before mirt_scene_upload                    */
+    MIRT_ERR_OUT_OF_MEMORY = -5,
+    MIRT_ERR_HIP = -6                 /* a HIP runtime call failed; see mirt_last_error()        */
+} mirt_status;
+
+/* cameraPos / cameraRot / focalLength / SCREEN_WIDTH / SCREEN_HEIGHT (raytracer.cpp:64-73,
+ * rasteriser.cpp:35-41). rot is GLM column-major: rot[c*3+r] == cameraRot[c][r]. */
+typedef struct mirt_view {
+    float pos[3];
+    float rot[9];
+    float focal;
+    int32_t width;
+    int32_t height;
+} mirt_view;
+
+/* class Light (TestModel.h:35-45), same field order and size (28 bytes). */
+typedef struct mirt_light {
+    float pos[3];
+    float color[3];
+    float intensity;
+} mirt_light;
+
+/* How the ray tracer finds each ray's candidate triangles.  All modes return identical results. */
+typedef enum mirt_rt_mode {
+    MIRT_RT_AUTO = 0,     /* brute force for small scenes, binned otherwise                          */
+    MIRT_RT_BRUTE = 1,    /* every ray tests every triangle (what ClosestIntersection does)         */
+    MIRT_RT_BINNED = 2    /* conservative screen-tile / light-cube binning, same accept arithmetic  */
+} mirt_rt_mode;
+
+/* Counters of the last render call (ray accounting follows SURVEY section 8(d)). */
+typedef struct mirt_stats {
+    uint64_t primary_rays;        /* width * rows rendered                                          */
+    uint64_t shadow_rays;         /* nlights * (pixels whose primary ray hit)                       */
+    uint64_t tests;               /* ray-triangle tests actually executed (0 if not counted)        */
+    float gpu_ms;                 /* hipEvent time of the call's device work on the library stream   */
+    float kernel_ms[8];           /* per-kernel time of the call when profiling is on (see below)    */
+    int32_t mode_used;            /* mirt_rt_mode actually used                                      */
+} mirt_stats;
+
+/* indices into mirt_stats.kernel_ms */
+enum { MIRT_K_PREP = 0, MIRT_K_BIN = 1, MIRT_K_TRACE = 2, MIRT_K_SHADE = 3,
+       MIRT_K_RASTER_SETUP = 4, MIRT_K_RASTER_FRAG = 5, MIRT_K_RASTER_RESOLVE = 6, MIRT_K_CLEAR = 7 };
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+
+/* Replaces nothing in the reference (it has no device).  Selects HIP device `device` (use the process's
+ * LOCAL_RANK under torch.distributed), checks it is gfx950, creates the library stream. */
+MIRT_API int mirt_init(int device);
+MIRT_API void mirt_shutdown(void);
+MIRT_API const char *mirt_last_error(void);
+MIRT_API int mirt_abi_version(void);
+/* When on, every kernel launch is bracketed by hipEvents on the library stream and mirt_stats.kernel_ms
+ * is filled (costs a few microseconds per launch; off by default). */
+MIRT_API int mirt_set_profiling(int on);
+/* Blocks until all work queued on the library stream has finished. */
+MIRT_API int mirt_sync(void);
+/* The library's hipStream_t (as void*), so a caller can order its own work after ours. */
+MIRT_API void *mirt_stream(void);
+
+/* ---- scene --------------------------------------------------------------------------------------- */
+
+/* Replaces the global `vector<Triangle> triangles` (raytracer.cpp:28, rasteriser.cpp:64): copies n
+ * triangles (n x 15 floats, reference AoS order) to the device and precomputes the per-triangle edge
+ * data.  `culled` (nullable, n bytes) is Triangle::isCulled of the rasteriser (rasteriser/Source/
+ * TestModel.h:18); the ray tracer ignores it.  The caller may free both arrays on return. */
+MIRT_API int mirt_scene_upload(const float *tris15, const uint8_t *culled, int n);
+/* Replaces the per-frame `triangles[i].isCulled = ...` writes of the rasteriser's Update()
+ * (rasteriser.cpp:404-447) for an already uploaded scene. */
+MIRT_API int mirt_scene_set_culled(const uint8_t *culled, int n);
+MIRT_API int mirt_scene_size(void);
+
+/* LoadTestModel (raytracer/Source/TestModel.h:51-192): writes the 30 Cornell-box triangles, returns 30. */
+MIRT_API int mirt_scene_cornell(float *tris15);
+/* Synthetic soup for the benchmark configs (no reference counterpart; generator defined in SURVEY
+ * section 8(d)): mt19937(seed), centres U[-1,1]^3, two edges U[-s,s]^3, colours U[0.15,0.75]^3,
+ * normal by the reference's Triangle::ComputeNormal rule. */
+MIRT_API int mirt_scene_soup(uint32_t seed, int n, float s, float *tris15);
+/* The cull step of the rasteriser's Update() (rasteriser.cpp:385-447, InCuboid :451-458), host side.
+ * flags: bit0 = BACKFACE_CULLING_ENABLED, bit1 = FRUSTUM_CULLING_ENABLED (both default on, :25-26). */
+MIRT_API int mirt_cull(const float *tris15, int n, const mirt_view *view, int flags, uint8_t *culled);
+
+/* ---- ray tracer: replaces Draw() + CalculateDOF() of raytracer.cpp:547-656 -------------------------- */
+
+/* One frame into host buffers.  out_xrgb (required) is the SDL surface's `pixels` (XRGB8888, the words
+ * PutPixelSDL stores, SDLauxiliary.h:75-80) with `pitch_bytes` per row; as in the reference only interior
+ * pixels x in [1,W-2], y in [1,H-2] are written (raytracer.cpp:618-620) -- border words are left untouched.
+ * out_rgb (nullable, W*H*3 floats) receives `pixelColours` (raytracer.cpp:88,600); out_index (nullable,
+ * W*H int32) receives closestIntersections[].triangleIndex, -1 where the primary ray missed (:98,243-247). */
+MIRT_API int mirt_raytrace(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                           int mode, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb, int32_t *out_index);
+
+/* Same frame, rows [y0, y1) only, into DEVICE buffers the caller owns (e.g. torch tensors), queued on the
+ * library stream without a host sync; used for screen-band sharding across GPUs and for benchmarking with
+ * resident buffers.  d_xrgb points at row 0 of a full-frame (or band-relative, see row_origin) surface:
+ * row y is written at d_xrgb + (y - row_origin) * pitch_bytes.  d_rgb / d_index (nullable) likewise use
+ * row stride W.  Interior-only rule as above (relative to the FULL frame). */
+MIRT_API int mirt_raytrace_device(const mirt_view *view, const mirt_light *lights, int nlights,
+                                  const float *indirect, int mode, int y0, int y1, int row_origin,
+                                  void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index);
+
+/* ---- rasteriser: replaces Update()'s clear + Draw() + CalculateDOF() of rasteriser.cpp:183-192,461-529 */
+
+/* One frame into host buffers.  Every word of out_xrgb is written: the whole surface is cleared to black
+ * (rasteriser.cpp:190) and interior pixels then receive the resolved colour (:491-519).  out_rgb (nullable)
+ * = pixelColours, out_zinv (nullable) = depthBuffer (1/z, 0 where nothing was drawn, :52,188), out_index
+ * (nullable) = index of the triangle that owns each pixel or -1. */
+MIRT_API int mirt_rasterise(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                            uint32_t *out_xrgb, int pitch_bytes, float *out_rgb, float *out_zinv,
+                            int32_t *out_index);
+
+/* Rows [y0, y1) into DEVICE buffers, queued on the library stream (see mirt_raytrace_device). */
+MIRT_API int mirt_rasterise_device(const mirt_view *view, const mirt_light *lights, int nlights,
+                                   const float *indirect, int y0, int y1, int row_origin,
+                                   void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_zinv, void *d_index);
+
+/* Counters / timings of the most recent render call. */
+MIRT_API int mirt_get_stats(mirt_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

@@ -1,0 +1,196 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (libmirt.so), against the CPU oracle and the
+reference's recorded outputs.  Bar (BASELINE.json north_star): closest-hit triangle index bit-exact, colours
+within 1e-4 per channel -- in practice the kernels reproduce the float colours bit for bit, which the tests
+also assert (it is what makes the 8-bit frame identical).
+"""
+import numpy as np
+import pytest
+
+import mirt
+from mirt_oracle import DEFAULT_LIGHT
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # per-channel colour tolerance stated by north_star
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    mirt.init(0)          # raises MirtError (fails loudly) when libmirt.so or the GPU is missing
+    yield
+    mirt.shutdown()
+
+
+def _rt_compare(oracle, tris, cam, rot, focal, W, H, lights, mode=mirt.RT_BRUTE, threads=16):
+    ref = oracle.raytrace(tris, cam, rot, focal, W, H, lights, threads=threads)
+    mirt.scene_upload(tris)
+    got = mirt.raytrace(mirt.make_view(cam, rot, focal, W, H), lights, mode=mode)
+    assert np.array_equal(got["index"], ref["index"]), "closest-hit index differs in %d pixels" % int((got["index"] != ref["index"]).sum())
+    assert np.max(np.abs(got["rgb"] - ref["rgb"])) <= TOL
+    assert np.array_equal(got["rgb"].view(np.uint32), ref["rgb"].view(np.uint32)), "float colours not bit-identical"
+    assert np.array_equal(got["xrgb"], ref["xrgb"])
+    assert got["stats"]["primary_rays"] == W * H
+    assert got["stats"]["shadow_rays"] == ref["nshadow"]
+    return got, ref
+
+
+def test_rt_cornell_500_matches_reference_hashes(oracle, golden):
+    """Config 1/2 at the reference's own size: the GPU frame reproduces the hashes recorded from the reference."""
+    g = golden["raytracer"]
+    tris = mirt.scene_cornell()
+    rot = oracle.rot_from_yaw(0.0, 1.0)
+    mirt.scene_upload(tris)
+    view = mirt.make_view(g["cam_pos"], rot, g["focal"], 500, 500)
+    lit = mirt.raytrace(view, np.array([g["light"]], np.float32), mode=mirt.RT_BRUTE)
+    assert "%016x" % oracle.fnv(lit["index"]) == g["index_fnv"]
+    assert "%016x" % oracle.fnv(lit["rgb"]) == g["with_light"]["rgb_fnv"]
+    assert "%016x" % oracle.fnv(lit["xrgb"]) == g["with_light"]["screen_fnv"]
+    unlit = mirt.raytrace(view, np.zeros((0, 7), np.float32), mode=mirt.RT_BRUTE)
+    assert "%016x" % oracle.fnv(unlit["index"]) == g["index_fnv"]
+    assert "%016x" % oracle.fnv(unlit["rgb"]) == g["no_light"]["rgb_fnv"]
+    assert "%016x" % oracle.fnv(unlit["xrgb"]) == g["no_light"]["screen_fnv"]
+    assert lit["stats"]["shadow_rays"] == 250000 and unlit["stats"]["shadow_rays"] == 0
+
+
+def test_rt_cornell_1080p(oracle):
+    """BASELINE config 2: Cornell box, 1920x1080, primary + shadow."""
+    _rt_compare(oracle, mirt.scene_cornell(), (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 540.0, 1920, 1080, DEFAULT_LIGHT)
+
+
+@pytest.mark.parametrize("yaw", [0.3, -1.1])
+def test_rt_cornell_rotated_camera(oracle, yaw):
+    _rt_compare(oracle, mirt.scene_cornell(), (0.2, -0.1, -2.5), oracle.rot_from_yaw(yaw, 1.0), 300.0, 640, 360, DEFAULT_LIGHT)
+
+
+def test_rt_three_lights_double_count_quirk(oracle):
+    """result2 += result without resetting result (raytracer.cpp:319-322) must be reproduced."""
+    lights = np.array([[0, -0.5, -0.7, 1, 1, 1, 14], [0.5, 0.3, -0.9, 1, 0.5, 0.2, 6], [-0.6, -0.2, 0.1, 0.3, 0.9, 0.4, 9]], np.float32)
+    _rt_compare(oracle, mirt.scene_cornell(), (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 128.0, 256, 256, lights)
+
+
+@pytest.mark.parametrize("n,W,H", [(1, 64, 64), (37, 200, 120), (1500, 320, 200), (5000, 256, 144)])
+def test_rt_soup_brute(oracle, n, W, H):
+    """Random soups (ragged sizes: n not a multiple of the LDS chunk, W not a multiple of 64)."""
+    tris = mirt.scene_soup(11 + n, n, 0.25 if n < 100 else 0.08)
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), H / 2.0, W, H, DEFAULT_LIGHT)
+
+
+def test_rt_miss_everywhere(oracle):
+    """Camera looking away: no hit anywhere -> index -1, black, zero shadow rays."""
+    tris = mirt.scene_cornell()
+    got, _ = _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(np.pi, 1.0), 100.0, 128, 96, DEFAULT_LIGHT)
+    assert (got["index"] == -1).all() and not got["xrgb"].any()
+
+
+def test_rt_border_left_untouched(oracle):
+    tris = mirt.scene_cornell()
+    mirt.scene_upload(tris)
+    W = H = 96
+    canvas = np.full((H, W + 5), 0xABCDEF01, np.uint32)          # pitch wider than the row
+    view = mirt.make_view((0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 48.0, W, H)
+    mirt.raytrace(view, DEFAULT_LIGHT, xrgb=canvas[:, :W], want_rgb=False, want_index=False)
+    assert (canvas[0] == 0xABCDEF01).all() and (canvas[-1] == 0xABCDEF01).all()
+    assert (canvas[:, 0] == 0xABCDEF01).all() and (canvas[:, W - 1:] == 0xABCDEF01).all()
+    ref = oracle.raytrace(tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 48.0, W, H, DEFAULT_LIGHT)
+    assert np.array_equal(canvas[1:-1, 1:W - 1], ref["xrgb"][1:-1, 1:-1])
+
+
+def test_rt_degenerate_inputs(oracle):
+    """Zero-area and edge-on triangles divide by zero in the reference (NaN/Inf always reject)."""
+    tris = mirt.scene_soup(5, 64, 0.3)
+    tris[3, 3:6] = tris[3, 0:3]                      # v1 == v0  -> zero area
+    tris[7, 6:9] = tris[7, 3:6]                      # v2 == v1
+    tris[9, 0:9] = np.tile(tris[9, 0:3], 3)          # a point
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 80.0, 160, 160, DEFAULT_LIGHT)
+
+
+def test_rt_huge_coordinates_take_exact_path(oracle):
+    """Operands beyond the pre-reject filter's proven range switch the kernel to the exact-only path."""
+    tris = mirt.scene_soup(6, 40, 0.3)
+    tris[5, 0:9] *= 1.0e12
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 64.0, 128, 128, DEFAULT_LIGHT)
+
+
+def test_rt_band_rendering_matches_full_frame(oracle):
+    """Rows [y0,y1) rendered as separate bands (what each GPU does when the frame is sharded) are byte-identical."""
+    import ctypes as C
+    tris = mirt.scene_soup(3, 300, 0.2)
+    mirt.scene_upload(tris)
+    W, H = 200, 120
+    view = mirt.make_view((0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 60.0, W, H)
+    full = mirt.raytrace(view, DEFAULT_LIGHT)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    d = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d), W * H * 4) == 0
+    assert hip.hipMemset(d, 0, W * H * 4) == 0
+    for (y0, y1) in [(0, 50), (50, 51), (51, 120)]:
+        mirt.raytrace_device(view, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_BRUTE, y0, y1, 0, d, W * 4)
+    mirt.sync()
+    out = np.zeros((H, W), np.uint32)
+    assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), d, W * H * 4, 2) == 0
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipFree(d)
+    assert np.array_equal(out, full["xrgb"])
+
+
+# ---- rasteriser --------------------------------------------------------------------------------------
+
+def _raster_compare(oracle, tris, cam, rot, focal, W, H, lights, cull_flags=3):
+    view = mirt.make_view(cam, rot, focal, W, H)
+    culled = mirt.cull(tris, view, cull_flags)
+    assert np.array_equal(culled, oracle.cull(tris, cam, rot, focal, W, H, cull_flags))
+    ref = oracle.rasterise(tris, culled, cam, rot, focal, W, H, lights)
+    mirt.scene_upload(tris, culled)
+    got = mirt.rasterise(view, lights)
+    assert np.array_equal(got["index"], ref["index"]), "owner triangle differs in %d pixels" % int((got["index"] != ref["index"]).sum())
+    assert np.array_equal(got["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+    assert np.max(np.abs(got["rgb"] - ref["rgb"])) <= TOL
+    assert np.array_equal(got["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    assert np.array_equal(got["xrgb"], ref["xrgb"])
+    return got, ref
+
+
+def test_raster_cornell_500_matches_reference_hashes(oracle, golden):
+    g = golden["rasteriser"]
+    tris = mirt.scene_cornell()
+    rot = oracle.rot_from_yaw(0.0, g["rot11"])
+    got, _ = _raster_compare(oracle, tris, g["cam_pos"], rot, g["focal"], 500, 500, np.array([g["light"]], np.float32))
+    assert int((got["depth"] > 0).sum()) == g["covered"]
+    assert "%016x" % oracle.fnv(got["depth"]) == g["depth_fnv"]
+    assert "%016x" % oracle.fnv(got["rgb"]) == g["rgb_fnv"]
+
+
+def test_raster_cornell_4k(oracle):
+    """BASELINE config 4: Cornell box, 3840x2160, camera (0,0,-3), cameraRot[1][1] = 1.01, focal = H."""
+    _raster_compare(oracle, mirt.scene_cornell(), (0, 0, -3), oracle.rot_from_yaw(0.0, 1.01), 2160.0, 3840, 2160, DEFAULT_LIGHT)
+
+
+@pytest.mark.parametrize("yaw,cam", [(0.4, (0.3, 0.1, -2.6)), (-0.7, (-0.5, 0.2, -2.2))])
+def test_raster_cornell_rotated(oracle, yaw, cam):
+    _raster_compare(oracle, mirt.scene_cornell(), cam, oracle.rot_from_yaw(yaw, 1.01), 400.0, 640, 400, DEFAULT_LIGHT)
+
+
+@pytest.mark.parametrize("n,W,H", [(1, 64, 64), (300, 320, 200), (4000, 400, 300)])
+def test_raster_soup(oracle, n, W, H):
+    """Soups in front of the camera (camera outside the cube): partially off-screen spans, depth ties."""
+    tris = mirt.scene_soup(21 + n, n, 0.3 if n < 10 else 0.1)
+    _raster_compare(oracle, tris, (0, 0, -3.5), oracle.rot_from_yaw(0.0, 1.01), float(H), W, H, DEFAULT_LIGHT, cull_flags=0)
+
+
+def test_raster_everything_culled(oracle):
+    tris = mirt.scene_cornell()
+    view = mirt.make_view((0, 0, -3), oracle.rot_from_yaw(0.0, 1.01), 100.0, 128, 128)
+    mirt.scene_upload(tris, np.ones(30, np.uint8))
+    got = mirt.rasterise(view, DEFAULT_LIGHT)
+    assert not got["xrgb"].any() and (got["index"] == -1).all() and not got["depth"].any()
+
+
+def test_errors_are_reported_not_fatal():
+    with pytest.raises(mirt.MirtError):
+        mirt.scene_upload(np.zeros((0, 15), np.float32))
+    view = mirt.make_view((0, 0, -2), np.eye(3, dtype=np.float32).ravel(), 10.0, 0, 10)
+    with pytest.raises(mirt.MirtError):
+        mirt.raytrace(view, DEFAULT_LIGHT)
