@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native render path (see BASELINE.json / SURVEY section 8(d)).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A "step" is one frame of the hot path over a synthetic scene whose inputs are already resident in HBM.
+Prints ONE JSON line (rank 0).  Workloads (BASELINE.json `configs`):
+    cornell1080  (default, configs[1]) Cornell box, 1920x1080, primary + DirectLight shadow rays
+    soup100k     (configs[2]) 100k random triangles, 1920x1080
+    raster4k     (configs[3]) rasteriser, Cornell box, 3840x2160
+    cornell500   (configs[0]) the reference's own 500x500 case
+    soup1m8k     (configs[4]) 1M random triangles, 7680x4320 (meant for 8 GPUs)
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the frame is split into N bands of
+rows; every rank renders its band and the XRGB bands are gathered on rank 0 over RCCL ("scaling": "strong").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"))
+
+import numpy as np  # noqa: E402
+
+LIGHT = np.array([[0.0, -0.5, -0.7, 1.0, 1.0, 1.0, 14.0]], np.float32)     # raytracer.cpp:116 / rasteriser.cpp:104
+INDIRECT = (0.2, 0.2, 0.2)                                                    # raytracer.cpp:81
+
+FLOP_PER_TEST = 60.0          # 57 add/mul + 3 div as written in raytracer.cpp:216-239
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: vector FP32 peak (counts FMA as 2; this path may not fuse)
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
+
+WORKLOADS = {
+    #  name         kind      scene                      W     H     cam            focal   rot11
+    "cornell1080": ("rt", ("cornell",), 1920, 1080, (0, 0, -2), 540.0, 1.0),
+    "cornell500": ("rt", ("cornell",), 500, 500, (0, 0, -2), 250.0, 1.0),
+    "soup100k": ("rt", ("soup", 1, 100000, 0.05), 1920, 1080, (0, 0, -2), 540.0, 1.0),
+    "soup1m8k": ("rt", ("soup", 2, 1000000, 0.02), 7680, 4320, (0, 0, -2), 2160.0, 1.0),
+    "raster4k": ("raster", ("cornell",), 3840, 2160, (0, 0, -3), 2160.0, 1.01),
+}
+
+
+def identity_rot(m11):
+    r = np.zeros(9, np.float32)
+    r[0] = r[8] = 1.0          # yaw = 0: cos = 1, sin = 0 (raytracer.cpp:377-382)
+    r[4] = m11
+    return r
+
+
+def band_of(rank, world, H):
+    """Rows [y0, y1) of rank `rank` when H rows are split into `world` contiguous bands."""
+    base, rem = divmod(H, world)
+    y0 = rank * base + min(rank, rem)
+    return y0, y0 + base + (1 if rank < rem else 0)
+
+
+def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0):
+    """The oracle (CPU restatement, oracle/mirt_oracle.c) timed on this host's cores on a bounded sample of
+    the same workload.  Test infrastructure: measured as a baseline, never used by the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from mirt_oracle import Oracle
+    o = Oracle()
+    cores = len(os.sched_getaffinity(0))
+    if kind == "raster":
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            o.rasterise(tris, culled, cam, rot, focal, W, H, LIGHT, want=())
+            reps += 1
+            if time.perf_counter() - t0 > min(budget_s, 6.0) or reps >= 5:
+                break
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": round(1.0 / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d full %dx%d frames, single thread (the reference's default for the rasteriser)" % (reps, W, H)}
+    # ray tracer: time a probe of rows first, then as many evenly spaced rows as fit the budget (bounded sample)
+    cores = min(cores, 64)                      # OpenMP over rows stops scaling long before 256 threads here
+    centre = H // 2
+    t0 = time.perf_counter()
+    r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=centre, y1=centre + 1, threads=cores, want=("xrgb",))
+    probe = max(time.perf_counter() - t0, 1e-4)
+    rows = int(max(cores, min(H, budget_s / probe)))
+    if rows >= H:
+        t0 = time.perf_counter()
+        r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, threads=cores, want=("xrgb",))
+        dt = time.perf_counter() - t0
+        rays = W * H + r["nshadow"]
+        sample = "full %dx%d frame" % (W, H)
+    else:
+        # one call over a contiguous band of `rows` rows around the image centre keeps all threads busy
+        ya = max(0, centre - rows // 2)
+        yb = min(H, ya + rows)
+        t0 = time.perf_counter()
+        r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=ya, y1=yb, threads=cores, want=("xrgb",))
+        dt = time.perf_counter() - t0
+        rays = W * (yb - ya) + r["nshadow"]
+        sample = "rows %d..%d of %d (central band), per-ray rate" % (ya, yb - 1, H)
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="cornell1080", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="auto", choices=["auto", "brute", "binned"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import mirt
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    mirt.init(local_rank)
+
+    kind, scene, W, H, cam, focal, rot11 = WORKLOADS[args.workload]
+    rot = identity_rot(rot11)
+    tris = mirt.scene_cornell() if scene[0] == "cornell" else mirt.scene_soup(scene[1], scene[2], scene[3])
+    view = mirt.make_view(cam, rot, focal, W, H)
+    culled = mirt.cull(tris, view, 3) if kind == "raster" else None
+    mirt.scene_upload(tris, culled)
+    mode = {"auto": mirt.RT_AUTO, "brute": mirt.RT_BRUTE, "binned": mirt.RT_BINNED}[args.mode]
+
+    steps = args.steps if args.steps is not None else (200 if len(tris) < 1000 else 3)
+    warmup = args.warmup if args.warmup is not None else (20 if len(tris) < 1000 else 1)
+
+    y0, y1 = band_of(rank, world, H)
+    dev = torch.device("cuda", local_rank)
+    band = torch.zeros((max(y1 - y0, 1), W), dtype=torch.int32, device=dev)          # this rank's XRGB rows
+    frame = torch.zeros((H, W), dtype=torch.int32, device=dev) if rank == 0 else None  # gathered frame (rank 0)
+    mirt_stream = torch.cuda.ExternalStream(mirt.load().mirt_stream(), device=dev)
+
+    def render():
+        if kind == "rt":
+            mirt.raytrace_device(view, LIGHT, INDIRECT, mode, y0, y1, y0, band.data_ptr(), W * 4)
+        else:
+            mirt.rasterise_device(view, LIGHT, INDIRECT, y0, y1, y0, band.data_ptr(), W * 4)
+
+    if world > 1:
+        sizes = [band_of(r, world, H) for r in range(world)]
+        gather_list = [frame[a:b] for (a, b) in sizes] if rank == 0 else None
+
+    def step():
+        render()
+        if world > 1:
+            # the band is complete on mirt's stream; order the gather after it, and the next render after the gather
+            torch.cuda.current_stream().wait_stream(mirt_stream)
+            dist.gather(band[: y1 - y0], gather_list, dst=0)
+            mirt_stream.wait_stream(torch.cuda.current_stream())
+
+    def fence():
+        mirt.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    st = mirt.stats()
+    t0 = time.perf_counter()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(mirt_stream)
+    for _ in range(steps):
+        step()
+    ev1.record(mirt_stream)
+    fence()
+    dt = time.perf_counter() - t0
+    gpu_total_ms = ev0.elapsed_time(ev1)        # HIP events on the stream the kernels run on
+
+    # whole-job numbers: MAX over ranks of the wall time, SUM over ranks of the rays
+    st = mirt.stats()
+    rays_rank = float(st["primary_rays"] + st["shadow_rays"]) if kind == "rt" else 0.0
+    tests_rank = float(st["tests"])
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([rays_rank, tests_rank, float(st["shadow_rays"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        rays_frame, tests_frame, shadow_frame = [float(x) for x in s.tolist()]
+    else:
+        rays_frame, tests_frame, shadow_frame = rays_rank, tests_rank, float(st["shadow_rays"])
+
+    # per-kernel durations of this rank: a separate profiled pass (events around every launch)
+    mirt.set_profiling(True)
+    kacc = {}
+    prof_steps = min(steps, 20)
+    for _ in range(prof_steps):
+        render()
+        mirt.sync()
+        for k, v in mirt.stats()["kernel_ms"].items():
+            kacc[k] = kacc.get(k, 0.0) + v
+    mirt.set_profiling(False)
+    kernel_ms = {k: v / prof_steps for k, v in kacc.items() if v > 0}
+
+    if rank == 0:
+        ms_per_step = dt / steps * 1e3
+        out = {
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
+            "frames_per_s": round(steps / dt, 3),
+            "gpu_ms_per_step_rank0": round(gpu_total_ms / steps, 5),
+            "kernel_ms_rank0": {k: round(v, 5) for k, v in kernel_ms.items()},
+        }
+        px = W * H
+        if kind == "rt":
+            out.update({
+                "metric": "Mrays/s (primary+shadow)", "unit": "Mrays/s", "dtype": "f32",
+                "value": round(rays_frame / (dt / steps) / 1e6, 3),
+                "config": {"workload": args.workload, "scene": "cornell-30" if scene[0] == "cornell" else "soup-%d-seed%d" % (scene[2], scene[1]),
+                           "triangles": int(len(tris)), "width": W, "height": H, "lights": 1,
+                           "primary_rays": W * H, "shadow_rays": int(shadow_frame), "mode": ["auto", "brute", "binned"][st["mode_used"]],
+                           "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
+            })
+            kt = kernel_ms.get("trace", 0.0)
+            algo_flop = tests_frame / world * FLOP_PER_TEST if tests_frame else rays_rank * len(tris) * FLOP_PER_TEST
+            ach = algo_flop / (kt * 1e-3) / 1e12 if kt > 0 else None
+            out["roofline"] = {"bound": "valu", "kernel": "k_rt_brute", "achieved": None if ach is None else round(ach, 3),
+                               "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None if ach is None else round(ach / PEAK_FP32_TFLOPS, 4),
+                               "traffic": None,
+                               "note": "FP32 VALU-bound (no contraction => no MFMA); algorithmic flops = rays x triangles x 60 per launch"}
+            algo_bytes = 4.0 * W * (y1 - y0) + 60.0 * len(tris)
+            if kt > 0:
+                out["roofline_hbm"] = {"bound": "hbm", "achieved": round(algo_bytes / (kt * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
+                                       "unit": "GB/s", "frac": round(algo_bytes / (kt * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "traffic": None}
+        else:
+            out.update({
+                "metric": "frames/s (rasteriser)", "unit": "frames/s", "dtype": "f32", "value": round(steps / dt, 3),
+                "config": {"workload": args.workload, "scene": "cornell-30", "triangles": int(len(tris)), "visible_triangles": int((culled == 0).sum()),
+                           "width": W, "height": H, "lights": 1, "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
+            })
+            # algorithmic bytes per frame: clear 8/px + fragments x 8 + resolve read 8/px + XRGB write 4/px
+            frag = 1.5 * px
+            algo_bytes = (8 + 8 + 4) * px + 8 * frag
+            tot = sum(kernel_ms.get(k, 0.0) for k in ("clear", "raster_setup", "raster_frag", "raster_resolve"))
+            if tot > 0:
+                out["roofline"] = {"bound": "hbm", "kernel": "clear+setup+frag+resolve", "achieved": round(algo_bytes / (tot * 1e-3) / 1e9, 3),
+                                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(algo_bytes / (tot * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                                   "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, tris, culled, W, H, cam, rot, focal)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    mirt.shutdown()
+
+
+if __name__ == "__main__":
+    main()

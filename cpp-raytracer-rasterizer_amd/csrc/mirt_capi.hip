@@ -3,6 +3,8 @@
 // every compute entry point returns MIRT_ERR_NO_DEVICE.
 #include "rt_common.hpp"
 #include "raster_common.hpp"
+#include "rt_binned.hpp"
+#include "scan.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +17,19 @@ namespace mirt {
 // kernels (rt_kernels.hip, raster_kernels.hip)
 __global__ void k_prep_origin(const float *, int, const float *, OriginRow *, OriginRow *, uint32_t *);
 template <int P> __global__ void k_rt_brute(const RtFrame);
+template <int P> __global__ void k_rt_small(const RtFrame, int);
+__global__ void k_bin_l0(const OriginRow *, const OriginRow *, int, BinSet, BinQueues);
+__global__ void k_bin_l1(const OriginRow *, const OriginRow *, int, BinSet, BinQueues);
+__global__ void k_bin_l2(const OriginRow *, const OriginRow *, int, BinSet, BinQueues);
+__global__ void k_bin_fill(BinSet, BinQueues);
+struct RtBinnedFrame {
+    RtFrame f;
+    BinSet bins;
+    uint32_t cam_base;
+    uint32_t light_base[MIRT_MAX_LIGHTS];
+    int tiles_x;
+};
+__global__ void k_rt_binned(const RtBinnedFrame);
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
 
 namespace {
@@ -58,6 +73,17 @@ struct Ctx {
     uint32_t *d_flags = nullptr;                 // [0] = unsafe, [2..3] = hit counter (u64)
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
+
+    // binned ray tracing: frame descriptors, per-bin offsets / cursors, candidate entries
+    BinFrameDesc *d_frames = nullptr;
+    uint32_t *d_bin_off = nullptr, *d_bin_fill = nullptr, *d_bin_sums = nullptr, *d_bin_counters = nullptr;
+    uint32_t *d_entries = nullptr;
+    uint32_t cap_bins = 0, cap_entries = 0;
+    unsigned long long *d_q1 = nullptr, *d_q2 = nullptr, *d_q2mask = nullptr;
+    uint32_t *d_qcounters = nullptr;
+    uint32_t cap_q1 = 0, cap_q2 = 0;
+    uint64_t bin_key = 0;
+    bool bin_key_valid = false;
 
     // staging for the host-buffer entry points
     void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr;
@@ -198,9 +224,32 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     float rmax = 0.0f;
     for (int i = 0; i < 9; i++) rmax = fmaxf(rmax, fabsf(view->rot[i]));
     const float dmax = 3.0f * rmax * fmaxf(fmaxf((float)view->width, (float)view->height), fabsf(view->focal));
-    bool safe = g.scene_finite && finite_below(view->pos, 3, MIRT_SAFE_MAG) && finite_below(view->rot, 9, 1.0e6f) &&
-                (dmax < 1.0e6f) && finite_below(origins, 3 * (1 + nlights), MIRT_SAFE_MAG);
+    bool safe = g.scene_finite && finite_below(view->rot, 9, 1.0e6f) && (dmax < 1.0e6f) &&
+                finite_below(origins, 3 * (1 + nlights), 1.0e8f);      // camera and light positions
     const uint32_t flags_init[4] = { safe ? 0u : 1u, 0u, 0u, 0u };
+
+    // ---- mode: brute force for small scenes, binned otherwise; unsafe operands always render exact brute ----
+    static const int auto_threshold = [] { const char *e = getenv("MIRT_BIN_THRESHOLD"); return e ? atoi(e) : 512; }();
+    static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 1; return (p == 2) ? 2 : 1; }();
+    bool binned = (mode == MIRT_RT_BINNED) || (mode == MIRT_RT_AUTO && g.n >= auto_threshold);
+    if (!safe) binned = false;
+    const int rows = y1 - y0;
+
+    // Small scenes (the reference's own 30-triangle Cornell box): one launch, every table built in LDS by the
+    // workgroup itself -- no origin-table kernel, no global loads inside the loops.
+    const size_t small_lds = 16 + (size_t)g.n * sizeof(OriginRow) * (2 + nlights);
+    if (!binned && small_lds <= 48 * 1024) {
+        HIP_TRY(hipMemsetAsync(g.d_flags, 0, 16, g.stream));
+        k_begin(MIRT_K_TRACE);
+        if (P == 2)
+            hipLaunchKernelGGL(k_rt_small<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), small_lds, g.stream, f, safe ? 0 : 1);
+        else
+            hipLaunchKernelGGL(k_rt_small<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), small_lds, g.stream, f, safe ? 0 : 1);
+        k_end(MIRT_K_TRACE);
+        HIP_TRY(hipGetLastError());
+        call_end();
+        return MIRT_OK;
+    }
 
     HIP_TRY(hipMemcpyAsync(g.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemcpyAsync(g.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
@@ -210,14 +259,163 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
                        g.d_tris, g.n, g.d_origins, g.d_cam_tab, g.d_light_tab, g.d_flags);
     k_end(MIRT_K_PREP);
 
-    static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 1; return (p == 2) ? 2 : 1; }();
-    const int rows = y1 - y0;
-    const size_t lds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
+    if (!binned) {
+        const size_t lds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
+        k_begin(MIRT_K_TRACE);
+        if (P == 2)
+            hipLaunchKernelGGL(k_rt_brute<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), lds, g.stream, f);
+        else
+            hipLaunchKernelGGL(k_rt_brute<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), lds, g.stream, f);
+        k_end(MIRT_K_TRACE);
+        HIP_TRY(hipGetLastError());
+        call_end();
+        return MIRT_OK;
+    }
+
+    // ---- binned: frame descriptors (camera tiles + six cube faces per light) ----
+    g.stats.mode_used = MIRT_RT_BINNED;
+    BinFrameDesc frames[MAX_BIN_FRAMES];
+    memset(frames, 0, sizeof frames);
+    const int W = view->width, H = view->height;
+    uint32_t nbins = 0;
+    {
+        BinFrameDesc &c = frames[0];
+        const float *R = view->rot;                       // column-major: column j = R[3j..3j+2]
+        const float hw = (float)W / 2.0f, hh = (float)H / 2.0f;
+        for (int i = 0; i < 3; i++) {
+            c.Pu[i] = -R[0 + i];
+            c.Pv[i] = -R[3 + i];
+            c.P0[i] = -(R[6 + i] * view->focal - R[0 + i] * hw - R[3 + i] * hh);
+        }
+        float dm = 0.0f;
+        for (int i = 0; i < 3; i++)
+            dm = fmaxf(dm, fabsf(R[0 + i]) * (hw + 1.0f) + fabsf(R[3 + i]) * (hh + 1.0f) + fabsf(R[6 + i]) * fabsf(view->focal));
+        c.dmax = dm;
+        c.ulo = 0.0f; c.vlo = 0.0f; c.du = (float)BIN_TILE; c.dv = (float)BIN_TILE;
+        c.pad_lo = 0.0f; c.pad_hi = -1.0f;                // bin i covers pixels 8i .. 8i+7 exactly
+        c.nbu = (W + BIN_TILE - 1) / BIN_TILE; c.nbv = (H + BIN_TILE - 1) / BIN_TILE;
+        c.j0 = y0 / BIN_TILE; c.j1 = (y1 + BIN_TILE - 1) / BIN_TILE;
+        c.base = 0; c.tab = 0;
+        nbins = (uint32_t)c.nbu * c.nbv;
+    }
+    int nframes = 1;
+    RtBinnedFrame bf;
+    memset(&bf, 0, sizeof bf);
+    for (int k = 0; k < nlights; k++) {
+        bf.light_base[k] = nbins;
+        for (int face = 0; face < 6; face++) {
+            BinFrameDesc &d = frames[nframes++];
+            const int ax = face >> 1;
+            d.P0[ax] = (face & 1) ? -1.0f : 1.0f;         // negD ~ s*e_k + u*e_(k+1) + v*e_(k+2)
+            d.Pu[(ax + 1) % 3] = 1.0f;
+            d.Pv[(ax + 2) % 3] = 1.0f;
+            d.dmax = 2.0f;
+            d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / CUBE_BINS; d.dv = 2.0f / CUBE_BINS;
+            d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
+            d.nbu = CUBE_BINS; d.nbv = CUBE_BINS; d.j0 = 0; d.j1 = CUBE_BINS;
+            d.base = nbins; d.tab = 1 + k;
+            nbins += CUBE_BINS * CUBE_BINS;
+        }
+    }
+    if (nbins + 1 > g.cap_bins) {
+        const size_t cap = (size_t)nbins + 1;
+        if ((rc = dev_realloc(&g.d_bin_off, cap))) { g.cap_bins = 0; return rc; }
+        if ((rc = dev_realloc(&g.d_bin_fill, cap))) { g.cap_bins = 0; return rc; }
+        if ((rc = dev_realloc(&g.d_bin_sums, cap / SCAN_ITEMS + 2))) { g.cap_bins = 0; return rc; }
+        g.cap_bins = (uint32_t)cap;
+        g.bin_key_valid = false;
+    }
+    if (!g.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_frames), sizeof(BinFrameDesc) * MAX_BIN_FRAMES));
+    if (!g.d_bin_counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_bin_counters), 16));
+    if (!g.d_entries) {
+        const size_t cap = (size_t)1 << 20;
+        if ((rc = dev_realloc(&g.d_entries, cap))) return rc;
+        g.cap_entries = (uint32_t)cap;
+    }
+    HIP_TRY(hipMemcpyAsync(g.d_frames, frames, sizeof(BinFrameDesc) * nframes, hipMemcpyHostToDevice, g.stream));
+
+    // work queues of the hierarchical binner: queue 1 can never hold more than one item per level-0 thread
+    BinQueues q;
+    memset(&q, 0, sizeof q);
+    const int L0 = BIN_COARSE * BIN_COARSE;
+    q.cam_cells_x = (uint32_t)((frames[0].nbu + L0 - 1) / L0);
+    q.cam_cell_y0 = (uint32_t)(frames[0].j0 / L0);
+    q.cam_cells = q.cam_cells_x * (uint32_t)((frames[0].j1 + L0 - 1) / L0 - frames[0].j0 / L0);
+    q.cells_per_tri = q.cam_cells + (uint32_t)(nframes - 1);
+    const size_t need_q1 = (size_t)g.n * q.cells_per_tri;
+    if (need_q1 > g.cap_q1) {
+        if ((rc = dev_realloc(&g.d_q1, need_q1))) { g.cap_q1 = 0; return rc; }
+        g.cap_q1 = (uint32_t)need_q1;
+    }
+    if (!g.d_q2) {
+        const size_t cap = (size_t)1 << 20;
+        if ((rc = dev_realloc(&g.d_q2, cap))) return rc;
+        if ((rc = dev_realloc(&g.d_q2mask, cap))) return rc;
+        g.cap_q2 = (uint32_t)cap;
+    }
+    if (!g.d_qcounters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_qcounters), 16));
+
+    uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
+    {
+        auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
+        mix(view, sizeof *view); mix(origins, sizeof(float) * 3 * (1 + nlights)); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4);
+    }
+
+    BinSet bs;
+    k_begin(MIRT_K_BIN);
+    for (int attempt = 0;; attempt++) {
+        bs.frames = g.d_frames; bs.nframes = nframes; bs.nbins = nbins;
+        bs.bin_off = g.d_bin_off; bs.bin_fill = g.d_bin_fill; bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
+        bs.counters = g.d_bin_counters;
+        q.q1 = g.d_q1; q.q2 = g.d_q2; q.q2mask = g.d_q2mask; q.cap1 = g.cap_q1; q.cap2 = g.cap_q2; q.counters = g.d_qcounters;
+
+        HIP_TRY(hipMemsetAsync(g.d_bin_off, 0, sizeof(uint32_t) * ((size_t)nbins + 1), g.stream));
+        HIP_TRY(hipMemsetAsync(g.d_bin_fill, 0, sizeof(uint32_t) * (size_t)nbins, g.stream));
+        HIP_TRY(hipMemsetAsync(g.d_qcounters, 0, 16, g.stream));
+        const unsigned l0_threads_blocks = (unsigned)((need_q1 + 255) / 256);
+        hipLaunchKernelGGL(k_bin_l0, dim3(l0_threads_blocks), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, q);
+        hipLaunchKernelGGL(k_bin_l1, dim3(2048), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, q);
+        hipLaunchKernelGGL(k_bin_l2, dim3(2048), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, q);
+        enqueue_exclusive_scan(g.d_bin_off, (int)nbins, g.d_bin_sums, g.d_bin_counters, g.stream);
+
+        // Queue 2 and the entry table are sized from counts only the device knows; they are read back (two tiny
+        // copies + one sync) only when the inputs that determine them changed since the last frame.
+        if (!g.bin_key_valid || g.bin_key != key) {
+            uint32_t qc[4] = { 0, 0, 0, 0 }, total = 0;
+            HIP_TRY(hipMemcpyAsync(qc, g.d_qcounters, 16, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipMemcpyAsync(&total, g.d_bin_counters, 4, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            bool redo = false;
+            if (qc[1] > g.cap_q2) {
+                const size_t cap = (size_t)qc[1] + qc[1] / 8 + 4096;
+                if ((rc = dev_realloc(&g.d_q2, cap))) { g.cap_q2 = 0; return rc; }
+                if ((rc = dev_realloc(&g.d_q2mask, cap))) { g.cap_q2 = 0; return rc; }
+                g.cap_q2 = (uint32_t)cap;
+                redo = true;                       // level 2 ran on a truncated queue: counts are incomplete
+            }
+            if (!redo && total > g.cap_entries) {
+                const size_t cap = (size_t)total + total / 8 + 4096;
+                if ((rc = dev_realloc(&g.d_entries, cap))) { g.cap_entries = 0; return rc; }
+                g.cap_entries = (uint32_t)cap;
+                bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
+            }
+            if (redo && attempt < 3) continue;
+            if (redo) return fail(MIRT_ERR_OUT_OF_MEMORY, "binning queues did not converge");
+            g.bin_key = key;
+            g.bin_key_valid = true;
+        }
+        hipLaunchKernelGGL(k_bin_fill, dim3(2048), dim3(256), 0, g.stream, bs, q);
+        break;
+    }
+    k_end(MIRT_K_BIN);
+
+    bf.f = f;
+    bf.bins = bs;
+    bf.cam_base = 0;
+    bf.tiles_x = frames[0].nbu;
+    const int tile_rows = frames[0].j1 - frames[0].j0;
     k_begin(MIRT_K_TRACE);
-    if (P == 2)
-        hipLaunchKernelGGL(k_rt_brute<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), lds, g.stream, f);
-    else
-        hipLaunchKernelGGL(k_rt_brute<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), lds, g.stream, f);
+    hipLaunchKernelGGL(k_rt_binned, dim3((bf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), 0, g.stream, bf);
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
@@ -276,7 +474,9 @@ extern "C" void mirt_shutdown(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
-                     (void *)g.d_flags, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv })
+                     (void *)g.d_flags, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
+                     (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries,
+                     (void *)g.d_q1, (void *)g.d_q2, (void *)g.d_q2mask, (void *)g.d_qcounters })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);

@@ -17,6 +17,7 @@
 //   k_raster_resolve  one thread per pixel: decode the winner, rebuild its pos3d, PixelShader, and write the
 //                     XRGB word (+ optional float colour / depth / index planes) with coalesced stores
 #include "raster_common.hpp"
+#include "scan.hpp"
 
 #include <limits.h>
 
@@ -53,8 +54,6 @@ __global__ __launch_bounds__(256) void k_raster_vertex(const RasterFrame f)
 }
 
 // ---- exclusive scan of row counts (3 passes, 1024 items per block) -----------------------------------
-constexpr int SCAN_ITEMS = 1024;
-
 __device__ __forceinline__ uint32_t block_exclusive_scan_256x4(uint32_t v[4], uint32_t *total)
 {
     __shared__ uint32_t s_wave[4];
@@ -146,16 +145,23 @@ __global__ __launch_bounds__(256) void k_raster_edges(const RasterFrame f)
     const int r0 = s.r0, r1 = s.r0 + rows;                           // band rows [r0, r1)
     const size_t base = f.scratch.row_base[t];
     if (base + (size_t)rows > f.scratch.cap_rows) { if (fld == 0 && e == 0) atomicExch(&f.scratch.counters[1], 1u); return; }
-    float *slots = f.scratch.slots;
-    int y = ya;
-    for (int k = 0; k < N; k++) {
-        if (y >= r0 && y < r1) {
-            float *slot = slots + ((base + (size_t)(y - r0)) * 3 + e) * SLOT_FIELDS;
-            slot[fld] = (fld == 0) ? __int_as_float(f2i_x86(cur)) : cur;      // result[i].x = current.x (:628)
-        }
-        if ((dir > 0 && y >= r1 - 1) || (dir < 0 && y <= r0)) break;  // later samples fall outside the band
-        cur += step;                                                  // :632-635, sequential on purpose
-        y += dir;
+    // Samples are y = ya, ya+dir, ... yb.  Only those inside the band are stored, but the float chain has to
+    // be walked from the edge's first sample: `skip` pure additions, then `cnt` store+add steps.
+    int skip, ystart, cnt;
+    if (dir > 0) { ystart = max(ya, r0); skip = ystart - ya; cnt = min(yb, r1 - 1) - ystart + 1; }
+    else if (dir < 0) { ystart = min(ya, r1 - 1); skip = ya - ystart; cnt = ystart - max(yb, r0) + 1; }
+    else { ystart = ya; skip = 0; cnt = (ya >= r0 && ya < r1) ? 1 : 0; }
+    if (cnt <= 0) return;
+#pragma unroll 8
+    for (int k = 0; k < skip; k++) cur += step;                      // :632-635, sequential on purpose
+    float *ptr = f.scratch.slots + ((base + (size_t)(ystart - r0)) * 3 + e) * SLOT_FIELDS + fld;
+    const ptrdiff_t stride = (ptrdiff_t)dir * 3 * SLOT_FIELDS;
+    if (fld == 0) {
+#pragma unroll 4
+        for (int k = 0; k < cnt; k++) { *ptr = __int_as_float(f2i_x86(cur)); ptr += stride; cur += step; }   // result[i].x = current.x (:628)
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < cnt; k++) { *ptr = cur; ptr += stride; cur += step; }
     }
 }
 
@@ -334,7 +340,6 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     auto begin = [&](int k) { if (ev) (void)hipEventRecord(ev[2 * k], stream); };
     auto end = [&](int k) { if (ev) (void)hipEventRecord(ev[2 * k + 1], stream); };
     const int band_rows = f.y1 - f.y0;
-    const int nblk = (f.n + SCAN_ITEMS - 1) / SCAN_ITEMS;
 
     begin(MIRT_K_CLEAR);
     if (hipMemsetAsync(s.keys, 0, (size_t)f.W * band_rows * sizeof(unsigned long long), stream) != hipSuccess) return MIRT_ERR_HIP;
@@ -343,9 +348,7 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     begin(MIRT_K_RASTER_SETUP);
     f.scratch = s;
     hipLaunchKernelGGL(k_raster_vertex, dim3((f.n + 255) / 256), dim3(256), 0, stream, f);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, stream, s.row_base, f.n, s.block_sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, s.block_sums, nblk, s.counters);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(256), 0, stream, s.row_base, f.n, s.block_sums, s.counters);
+    enqueue_exclusive_scan(s.row_base, f.n, s.block_sums, s.counters, stream);
 
     // The slot / span tables are sized from the total row count.  It is read back (one 4-byte copy + sync)
     // only when the frame's geometry inputs changed since the last call; otherwise last frame's count holds.

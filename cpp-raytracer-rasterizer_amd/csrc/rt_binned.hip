@@ -1,0 +1,256 @@
+// rt_binned.hip -- binning kernels and the binned ray-trace kernel (see rt_binned.hpp for the argument why
+// the candidate reduction cannot change any result).
+#include "rt_binned.hpp"
+
+#include <float.h>
+
+namespace mirt {
+
+// ---- hierarchical binning: three uniform levels, a work queue between them -----------------------------
+//
+//   level 0  one THREAD per (triangle, frame, 64x64-bin cell): one rectangle test; survivors -> queue 1
+//   level 1  one WAVE per queue-1 item, lane = one of the cell's 8x8 coarse cells (8x8 bins each) -> queue 2
+//   level 2  one WAVE per queue-2 item, lane = one of the coarse cell's 64 bins: count per bin, and keep the
+//            wave's 64-bit pass mask so the fill pass (after the scan) replays it without re-testing
+// Every level runs the same conservative rect_may_hit(); all lanes of a wave do the same amount of work, so
+// there is no divergence however uneven the triangle sizes are.  Queue items are packed
+//   tri(32) | frame(8) | cell_x(12) | cell_y(12).
+constexpr int BIN_L0 = BIN_COARSE * BIN_COARSE;       // 64 bins per level-0 cell side
+
+__device__ __forceinline__ unsigned long long pack_item(uint32_t tri, uint32_t frame, uint32_t cx, uint32_t cy)
+{
+    return ((unsigned long long)tri << 32) | ((unsigned long long)frame << 24) | ((unsigned long long)cx << 12) | cy;
+}
+
+__device__ __forceinline__ const OriginRow &row_of(const BinFrameDesc &fr, const OriginRow *cam_tab, const OriginRow *light_tab,
+                                                   int n, uint32_t tri)
+{
+    return (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
+}
+
+// rectangle of bins [i0,i1) x [j0,j1) in the frame's (u,v) parameters
+__device__ __forceinline__ bool bins_may_hit(const TriBinFns &t, const BinFrameDesc &fr, int i0, int i1, int j0, int j1)
+{
+    const float u0 = fr.ulo + (float)i0 * fr.du + fr.pad_lo, u1 = fr.ulo + (float)i1 * fr.du + fr.pad_hi;
+    const float v0 = fr.vlo + (float)j0 * fr.dv + fr.pad_lo, v1 = fr.vlo + (float)j1 * fr.dv + fr.pad_hi;
+    return rect_may_hit(t, u0, u1, v0, v1);
+}
+
+__global__ __launch_bounds__(256) void k_bin_l0(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
+                                                int n, BinSet bs, BinQueues q)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tri = id / q.cells_per_tri;
+    if (tri >= (uint32_t)n) return;
+    // which (frame, level-0 cell) this thread owns: frame 0 has cam_cells cells, every other frame exactly one
+    const uint32_t c = id - tri * q.cells_per_tri;
+    uint32_t frame, cx, cy;
+    if (c < q.cam_cells) { frame = 0; cx = c % q.cam_cells_x; cy = q.cam_cell_y0 + c / q.cam_cells_x; }
+    else { frame = 1 + (c - q.cam_cells); cx = 0; cy = 0; }
+    const BinFrameDesc &fr = bs.frames[frame];
+    const TriBinFns t = make_bin_fns(row_of(fr, cam_tab, light_tab, n, tri), fr);
+    const int i0 = cx * BIN_L0, i1 = min((int)(cx + 1) * BIN_L0, fr.nbu);
+    const int j0 = max((int)cy * BIN_L0, fr.j0), j1 = min((int)(cy + 1) * BIN_L0, fr.j1);
+    if (j1 <= j0 || !bins_may_hit(t, fr, i0, i1, j0, j1)) return;
+    const uint32_t slot = atomicAdd(&q.counters[0], 1u);
+    if (slot < q.cap1) q.q1[slot] = pack_item(tri, frame, cx, cy);
+    else atomicExch(&q.counters[3], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_bin_l1(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
+                                                int n, BinSet bs, BinQueues q)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t count = min(q.counters[0], q.cap1);
+    for (uint32_t it = wave_id; it < count; it += nwaves) {
+        const unsigned long long item = q.q1[it];
+        const uint32_t tri = (uint32_t)(item >> 32), frame = (uint32_t)(item >> 24) & 0xffu;
+        const uint32_t cx = (uint32_t)(item >> 12) & 0xfffu, cy = (uint32_t)item & 0xfffu;
+        const BinFrameDesc &fr = bs.frames[frame];
+        const TriBinFns t = make_bin_fns(row_of(fr, cam_tab, light_tab, n, tri), fr);
+        const uint32_t ccx = cx * BIN_COARSE + (lane & 7), ccy = cy * BIN_COARSE + (lane >> 3);   // coarse cell
+        const int i0 = ccx * BIN_COARSE, i1 = min((int)(ccx + 1) * BIN_COARSE, fr.nbu);
+        const int j0 = max((int)ccy * BIN_COARSE, fr.j0), j1 = min((int)(ccy + 1) * BIN_COARSE, fr.j1);
+        const bool pass = i0 < fr.nbu && j1 > j0 && bins_may_hit(t, fr, i0, i1, j0, j1);
+        const unsigned long long m = __ballot(pass);
+        if (m == 0ull) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&q.counters[1], (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (pass) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < q.cap2) q.q2[slot] = pack_item(tri, frame, ccx, ccy);
+            else atomicExch(&q.counters[3], 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_l2(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
+                                                int n, BinSet bs, BinQueues q)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t count = min(q.counters[1], q.cap2);
+    for (uint32_t it = wave_id; it < count; it += nwaves) {
+        const unsigned long long item = q.q2[it];
+        const uint32_t tri = (uint32_t)(item >> 32), frame = (uint32_t)(item >> 24) & 0xffu;
+        const uint32_t ccx = (uint32_t)(item >> 12) & 0xfffu, ccy = (uint32_t)item & 0xfffu;
+        const BinFrameDesc &fr = bs.frames[frame];
+        const TriBinFns t = make_bin_fns(row_of(fr, cam_tab, light_tab, n, tri), fr);
+        const int i = ccx * BIN_COARSE + (lane & 7), j = ccy * BIN_COARSE + (lane >> 3);
+        const bool pass = i < fr.nbu && j >= fr.j0 && j < fr.j1 && bins_may_hit(t, fr, i, i + 1, j, j + 1);
+        if (pass) atomicAdd(&bs.bin_off[fr.base + (uint32_t)j * fr.nbu + i], 1u);     // counts, scanned in place afterwards
+        const unsigned long long m = __ballot(pass);
+        if (lane == 0) q.q2mask[it] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_fill(BinSet bs, BinQueues q)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t count = min(q.counters[1], q.cap2);
+    for (uint32_t it = wave_id; it < count; it += nwaves) {
+        const unsigned long long m = q.q2mask[it];
+        if (!((m >> lane) & 1ull)) continue;
+        const unsigned long long item = q.q2[it];
+        const uint32_t tri = (uint32_t)(item >> 32), frame = (uint32_t)(item >> 24) & 0xffu;
+        const uint32_t ccx = (uint32_t)(item >> 12) & 0xfffu, ccy = (uint32_t)item & 0xfffu;
+        const BinFrameDesc &fr = bs.frames[frame];
+        const uint32_t bin = fr.base + (ccy * BIN_COARSE + (lane >> 3)) * fr.nbu + ccx * BIN_COARSE + (lane & 7);
+        const uint32_t slot = bs.bin_off[bin] + atomicAdd(&bs.bin_fill[bin], 1u);
+        if (slot < bs.cap_entries) bs.entries[slot] = tri;
+        else atomicExch(&bs.counters[1], 1u);
+    }
+}
+
+// ---- k_rt_binned: fused primary + shadow + shade + resolve over the binned candidates ---------------
+//
+// Workgroup = 256 threads = 4 wave64; each wave owns one 8x8-pixel tile (= one camera bin), the block a
+// 16x16 area.  Primary rays: the tile's candidate rows are gathered 64 at a time into the wave's LDS slice
+// (one lane loads one candidate's 48-byte origin row), then every lane walks them with broadcast reads -- the
+// same inner loop as brute force.  Shadow rays leave the light in incoherent directions, so every lane walks
+// the list of its own light-cube bin straight from global memory (the tables live in L2 / Infinity Cache).
+struct RtBinnedFrame {
+    RtFrame f;
+    BinSet bins;
+    uint32_t cam_base;                       // bin base of the camera frame
+    uint32_t light_base[MIRT_MAX_LIGHTS];    // bin base of face 0 of each light
+    int tiles_x;                             // camera bins per row (nbu)
+};
+
+// order-independent form of the reference's sequential ">=" update (raytracer.cpp:243-247):
+// smaller distance wins, equal distance -> larger triangle index wins
+__device__ __forceinline__ bool closer(float dist, int idx, float best_d, int best_i)
+{
+    return dist < best_d || (dist == best_d && idx > best_i);
+}
+
+__global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
+{
+    const RtFrame &f = bf.f;
+    __shared__ __attribute__((aligned(16))) float4 s_rows[4][64 * 3];
+    __shared__ uint32_t s_idx[4][64];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = (int)blockIdx.x * 2 + (wave & 1);
+    const int ty = f.y0 / BIN_TILE + (int)blockIdx.y * 2 + (wave >> 1);
+    const int x = tx * BIN_TILE + (lane & 7), y = ty * BIN_TILE + (lane >> 3);
+    const bool tile_ok = tx < bf.tiles_x && ty * BIN_TILE < f.y1;
+    const bool ok = tile_ok && x < f.W && y >= f.y0 && y < f.y1;
+    const v3 cam = ld3(f.cam);
+
+    // d = (x - W/2, y - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
+    const v3 d = V3((float)x - (float)f.W / 2.0f, (float)y - (float)f.H / 2.0f, f.focal);
+    const v3 nd = neg3(mat3_mul_vec(f.rot, d));
+    float best_d = FLT_MAX;
+    int best_i = -1;
+    v3 pos = V3(0.0f, 0.0f, 0.0f);
+
+    if (tile_ok) {
+        const uint32_t bin = bf.cam_base + (uint32_t)ty * bf.tiles_x + tx;
+        const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
+        for (uint32_t base = beg; base < end; base += 64) {
+            const int cnt = (int)min(64u, end - base);
+            if (lane < cnt) {
+                const uint32_t idx = bf.bins.entries[base + lane];
+                const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
+                s_idx[wave][lane] = idx;
+                s_rows[wave][3 * lane] = src[0];
+                s_rows[wave][3 * lane + 1] = src[1];
+                s_rows[wave][3 * lane + 2] = src[2];
+            }
+            // wave-private LDS slice: the wave's own writes are visible to it after the LDS counter drains
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int j = 0; j < cnt; j++) {
+                const float4 r0 = s_rows[wave][3 * j], r1 = s_rows[wave][3 * j + 1], r2 = s_rows[wave][3 * j + 2];
+                const TestDots td = test_dots(r0, r1, r2, nd);
+                if (maybe_hit(td)) {
+                    const int idx = (int)s_idx[wave][j];
+                    v3 hp;
+                    float dist;
+                    if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, cam, &hp, &dist))
+                        if (closer(dist, idx, best_d, best_i)) { best_d = dist; best_i = idx; pos = hp; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+
+    const bool hit = ok && best_i >= 0;
+    {
+        const unsigned long long m = __popcll(__ballot(hit));
+        if (lane == 0 && m) atomicAdd(f.hit_count, m);
+    }
+    if (!ok) return;
+
+    v3 avg = V3(0.0f, 0.0f, 0.0f);
+    if (hit) {
+        const float *t = f.tris15 + (size_t)15 * best_i;
+        const v3 nDir = normalize3(ld3(t + 9));            // (:300)
+        const v3 tcol = ld3(t + 12);
+        v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < f.nlights; k++) {
+            const v3 L = ld3(f.lpos[k]);
+            v3 rd;
+            float r;
+            v3 D = light_term(f, k, pos, nDir, &rd, &r);
+            const float thr = r * 0.99f;                   // (:313)
+            const uint32_t bin = cube_bin_of(rd, bf.light_base[k]);
+            const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
+            const OriginRow *tab = f.light_tab + (size_t)k * f.n;
+            for (uint32_t e = beg; e < end; e++) {
+                const uint32_t idx = bf.bins.entries[e];
+                const float4 *src = reinterpret_cast<const float4 *>(tab + idx);
+                const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+                const TestDots td = test_dots(r0, r1, r2, rd);   // negD = rDir (:310, :229)
+                if (maybe_hit(td)) {
+                    v3 hp;
+                    float dist;
+                    if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, L, &hp, &dist) && dist < thr) {
+                        D = V3(0.0f, 0.0f, 0.0f);          // occluded (:313-314); any-hit is exact
+                        break;
+                    }
+                }
+            }
+            result = add3(result, D);                      // (:319)
+            result2 = add3(result2, result);               // (:322)
+        }
+        const v3 Dl = mul3(result2, tcol);                 // (:325-326)
+        const v3 T = add3(Dl, ld3(f.indirect));            // (:584-586)
+        avg = add3(avg, mul3(tcol, T));                    // (:587-591)
+    }
+    avg = div3s(avg, 1.0f);                                // (:599)
+    const size_t px = (size_t)y * f.W + x;
+    if (f.rgb) st3(f.rgb + 3 * px, avg);
+    if (f.index) f.index[px] = best_i;
+    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)    // (:618-620)
+        f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+}
+
+}  // namespace mirt

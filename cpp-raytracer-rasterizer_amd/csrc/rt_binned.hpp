@@ -1,0 +1,136 @@
+// rt_binned.hpp -- result-preserving candidate reduction for the ray tracer.
+//
+// Brute force tests every ray against every triangle (what ClosestIntersection does); at 100k triangles that
+// is ~10^11 tests per frame.  The accept test of the reference,
+//     u + v <= 1 && u >= 0 && v >= 0 && t >= 0,  u = be2d/e1e2d, v = e1bd/e1e2d, t = e1e2b/e1e2d,
+// only looks at the signs of three functions that are LINEAR in the ray direction negD:
+//     e1e2d = e1e2 . negD,   be2d = be2 . negD,   e1bd = e1b . negD         (raytracer.cpp:232-234)
+// so for a family of rays negD ~ P0 + u*Pu + v*Pv (all rays of one origin through a 2-D parameter grid) each
+// of them is an affine "edge function" of (u, v), and a rectangle of the grid can contain an accepted ray only
+// if the corner bounds of those functions allow it.  That is a conservative tile test with no projection and
+// no clipping, valid for triangles beside or behind the origin too.  Two families are used:
+//   * the camera:  negD = -(R0*(x - W/2) + R1*(y - H/2) + R2*f), (u, v) = pixel (x, y); bins = 8x8-pixel tiles;
+//   * each light:  six cube faces, negD = rDir ~ s*e_k + u*e_k1 + v*e_k2 with (u, v) in [-1,1]^2; bins = a
+//     regular B x B grid per face.
+// Every ray then tests only the triangles of its bin, with the SAME filter + exact arithmetic as brute force
+// (rt_common.hpp), so accepted hits and their distances are bit-identical; the closest-hit tie rule (">=" in
+// index order, raytracer.cpp:243) is restated order-independently as (min distance, then max index).
+//
+// Margins: a rectangle keeps a triangle unless an edge function is provably below -m (resp. above +m) on all
+// of it, with m = 2^-17 * (|g.x|+|g.y|+|g.z|) * dmax + 2^-20.  dmax bounds |negD| components over the family,
+// so 2^-17*M is >100x the worst float rounding of the reference's own dot product (<= 4 ulp of M) and of the
+// bound evaluation; the 2^-20 covers the filter's absolute threshold (2^-22, scaled by <= sqrt(3) on cube faces).
+#pragma once
+
+#include "rt_common.hpp"
+
+namespace mirt {
+
+constexpr int BIN_TILE = 8;            // camera bins are 8x8 pixels = one wave64
+constexpr int BIN_COARSE = 8;          // coarse cell = 8x8 fine bins (hierarchical test)
+constexpr int CUBE_BINS = 64;          // per-face light-cube grid is CUBE_BINS x CUBE_BINS
+constexpr int MAX_BIN_FRAMES = 1 + 6 * MIRT_MAX_LIGHTS;
+
+struct BinFrameDesc {
+    float P0[3], Pu[3], Pv[3];   // negD ~ P0 + u*Pu + v*Pv
+    float ulo, vlo, du, dv;      // bin (i,j) covers u in [ulo + i*du + pad_lo, ulo + (i+1)*du + pad_hi]
+    float pad_lo, pad_hi;
+    float dmax;                  // bound on |negD| components over the family
+    int nbu, nbv;                // fine bins along u and v
+    int j0, j1;                  // rows of bins to build: [j0, j1)
+    uint32_t base;               // index of this frame's bin (0,0) in the global bin arrays
+    int tab;                     // origin table: 0 = camera, 1 + k = light k
+};
+
+struct BinSet {
+    const BinFrameDesc *frames;   // device array
+    int nframes;
+    uint32_t nbins;               // total bins over all frames
+    uint32_t *bin_off;            // nbins + 1: exclusive scan of the counts (bin_off[nbins] = total entries)
+    uint32_t *bin_fill;           // nbins: fill cursors
+    uint32_t *entries;            // candidate triangle indices
+    uint32_t cap_entries;
+    uint32_t *counters;           // [0] total entries, [1] overflow flag
+};
+
+// Work queues of the hierarchical binner (rt_binned.hip).  counters: [0] queue-1 items, [1] queue-2 items,
+// [3] overflow flag.
+struct BinQueues {
+    unsigned long long *q1, *q2, *q2mask;
+    uint32_t cap1, cap2;
+    uint32_t *counters;
+    uint32_t cells_per_tri;      // level-0 cells per triangle over all frames
+    uint32_t cam_cells, cam_cells_x, cam_cell_y0;
+};
+
+// affine edge function over (u,v) with its safety margin
+struct EdgeFn { float c0, cu, cv, m; };
+
+__device__ __forceinline__ EdgeFn make_edge_fn(float gx, float gy, float gz, const BinFrameDesc &fr)
+{
+    EdgeFn e;
+    e.c0 = gx * fr.P0[0] + gy * fr.P0[1] + gz * fr.P0[2];
+    e.cu = gx * fr.Pu[0] + gy * fr.Pu[1] + gz * fr.Pu[2];
+    e.cv = gx * fr.Pv[0] + gy * fr.Pv[1] + gz * fr.Pv[2];
+    e.m = 7.62939453125e-06f * ((fabsf(gx) + fabsf(gy) + fabsf(gz)) * fr.dmax) + 9.5367431640625e-07f;
+    return e;
+}
+
+struct TriBinFns { EdgeFn n, p, q, s; float nb; };
+
+__device__ __forceinline__ TriBinFns make_bin_fns(const OriginRow &r, const BinFrameDesc &fr)
+{
+    TriBinFns t;
+    t.n = make_edge_fn(r.r0.x, r.r0.y, r.r0.z, fr);
+    t.p = make_edge_fn(r.r1.x, r.r1.y, r.r1.z, fr);
+    t.q = make_edge_fn(r.r2.x, r.r2.y, r.r2.z, fr);
+    // slack function e1e2d - be2d - e1bd, bounded term by term (keeps the margin honest under cancellation)
+    t.s.c0 = t.n.c0 - t.p.c0 - t.q.c0;
+    t.s.cu = t.n.cu - t.p.cu - t.q.cu;
+    t.s.cv = t.n.cv - t.p.cv - t.q.cv;
+    t.s.m = 2.0f * (t.n.m + t.p.m + t.q.m);      // also absorbs the filter's D*2^-20 relative slack
+    t.nb = r.r0.w;
+    return t;
+}
+
+__device__ __forceinline__ void fn_range(const EdgeFn &e, float u0, float u1, float v0, float v1, float *lo, float *hi)
+{
+    const float a0 = e.cu * u0, a1 = e.cu * u1, b0 = e.cv * v0, b1 = e.cv * v1;
+    *hi = e.c0 + fmaxf(a0, a1) + fmaxf(b0, b1);
+    *lo = e.c0 + fminf(a0, a1) + fminf(b0, b1);
+}
+
+// May some ray with (u,v) in the rectangle be accepted by the reference's test?  (conservative)
+__device__ __forceinline__ bool rect_may_hit(const TriBinFns &t, float u0, float u1, float v0, float v1)
+{
+    float nlo, nhi, plo, phi, qlo, qhi, slo, shi;
+    fn_range(t.n, u0, u1, v0, v1, &nlo, &nhi);
+    fn_range(t.p, u0, u1, v0, v1, &plo, &phi);
+    fn_range(t.q, u0, u1, v0, v1, &qlo, &qhi);
+    fn_range(t.s, u0, u1, v0, v1, &slo, &shi);
+    const float T = 2.384185791015625e-07f;      // |e1e2b| below 2^-22 may underflow t to +-0, which passes t >= 0
+    const bool pos = (nhi > -t.n.m) && (phi >= -t.p.m) && (qhi >= -t.q.m) && (shi >= -t.s.m) && (t.nb > -T);
+    const bool neg = (nlo < t.n.m) && (plo <= t.p.m) && (qlo <= t.q.m) && (slo <= t.s.m) && (t.nb < T);
+    return pos || neg;
+}
+
+// Which light-cube face and bin a shadow ray with negD = rd belongs to.  Returns the global bin index.
+__device__ __forceinline__ uint32_t cube_bin_of(v3 rd, uint32_t face_base0 /* base of face 0 of this light */)
+{
+    const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
+    int k;
+    float m, a, b, sgn;
+    if (ax >= ay && ax >= az) { k = 0; m = ax; sgn = rd.x; a = rd.y; b = rd.z; }
+    else if (ay >= az) { k = 1; m = ay; sgn = rd.y; a = rd.z; b = rd.x; }
+    else { k = 2; m = az; sgn = rd.z; a = rd.x; b = rd.y; }
+    const int face = 2 * k + (sgn < 0.0f ? 1 : 0);
+    // u, v in [-1,1]; NaN (degenerate ray, never accepted by any triangle) falls into bin 0
+    const float u = a / m, v = b / m;
+    int i = (int)floorf((u + 1.0f) * (0.5f * CUBE_BINS));
+    int j = (int)floorf((v + 1.0f) * (0.5f * CUBE_BINS));
+    i = min(max(i, 0), CUBE_BINS - 1);
+    j = min(max(j, 0), CUBE_BINS - 1);
+    return face_base0 + (uint32_t)face * (CUBE_BINS * CUBE_BINS) + (uint32_t)j * CUBE_BINS + (uint32_t)i;
+}
+
+}  // namespace mirt

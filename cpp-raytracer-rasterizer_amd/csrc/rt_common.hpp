@@ -40,7 +40,8 @@ MIRT_HD OriginRow make_origin_row(const float *t15, v3 S)
 
 MIRT_HD bool origin_row_safe(const OriginRow &r)
 {
-    float m = fmaxf(fmaxf(fmaxf(fabsf(r.r0.x), fabsf(r.r0.y)), fmaxf(fabsf(r.r0.z), fabsf(r.r0.w))),
+    // r0.w (e1e2b) only feeds t = e1e2b / e1e2d and sign tests, so its magnitude is unconstrained
+    float m = fmaxf(fmaxf(fmaxf(fabsf(r.r0.x), fabsf(r.r0.y)), fabsf(r.r0.z)),
                     fmaxf(fmaxf(fmaxf(fabsf(r.r1.x), fabsf(r.r1.y)), fabsf(r.r1.z)),
                           fmaxf(fmaxf(fabsf(r.r2.x), fabsf(r.r2.y)), fabsf(r.r2.z))));
     return m < MIRT_SAFE_MAG;   // false for NaN too

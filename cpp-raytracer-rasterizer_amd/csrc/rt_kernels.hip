@@ -185,6 +185,185 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
     }
 }
 
+// ---- k_rt_small: the whole scene lives in LDS -----------------------------------------------------------
+//
+// For scenes like the reference's own Cornell box (30 triangles) one workgroup builds every table it needs
+// itself -- the origin rows for the camera and each light and the {v0, e1, e2} the exact path reads -- so the
+// frame is ONE kernel launch with no global loads inside the loops and a single barrier; waves that miss
+// everything retire early.  LDS: n * 48 B * (2 + nlights).
+struct SmallGeo { float4 g0, g1, g2; };   // {v0.xyz, e1.x}, {e1.y, e1.z, e2.x, e2.y}, {e2.z, -, -, -}
+
+__device__ __forceinline__ bool exact_hit_lds(const TestDots &d, float e1e2b, const float4 *geo, v3 start, v3 *pos, float *dist)
+{
+    const float t = e1e2b / d.den, u = d.pu / d.den, v = d.qv / d.den;      // raytracer.cpp:237
+    if (u + v <= 1.0f && u >= 0.0f && v >= 0.0f && t >= 0.0f) {             // :239
+        const float4 g0 = geo[0], g1 = geo[1], g2 = geo[2];
+        const v3 v0 = V3(g0.x, g0.y, g0.z), e1 = V3(g0.w, g1.x, g1.y), e2 = V3(g1.z, g1.w, g2.x);
+        const v3 p = add3(add3(v0, scale3(e1, u)), scale3(e2, v));          // :241
+        *pos = p;
+        *dist = distance3(start, p);                                         // :242
+        return true;
+    }
+    return false;
+}
+
+template <int P, bool FILTER>
+__device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam, const float4 *s_light, const float4 *s_geo)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int y = f.y0 + (int)blockIdx.y * 4 + wave;
+    if (y >= f.y1) return;
+    const v3 cam = ld3(f.cam);
+    const float halfW = (float)f.W / 2.0f, halfH = (float)f.H / 2.0f;
+    const int n = f.n;
+
+    int xs[P];
+    bool ok[P];
+    v3 nd[P], pos[P];
+    float best_d[P];
+    int best_i[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        xs[p] = ((int)blockIdx.x * P + p) * 64 + lane;
+        ok[p] = xs[p] < f.W;
+        const v3 d = V3((float)xs[p] - halfW, (float)y - halfH, f.focal);   // raytracer.cpp:579
+        nd[p] = neg3(mat3_mul_vec(f.rot, d));                                // :580, :229
+        best_d[p] = FLT_MAX;
+        best_i[p] = -1;
+        pos[p] = V3(0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll 2
+    for (int j = 0; j < n; j++) {
+        const float4 r0 = s_cam[3 * j], r1 = s_cam[3 * j + 1], r2 = s_cam[3 * j + 2];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const TestDots d = test_dots(r0, r1, r2, nd[p]);
+            if (!FILTER || maybe_hit(d)) {
+                v3 hp;
+                float dist;
+                if (exact_hit_lds(d, r0.w, s_geo + 3 * j, cam, &hp, &dist))
+                    if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = j; pos[p] = hp; }   // :243-247
+            }
+        }
+    }
+
+    bool hit[P];
+    bool any_hit = false;
+#pragma unroll
+    for (int p = 0; p < P; p++) { hit[p] = ok[p] && best_i[p] >= 0; any_hit |= hit[p]; }
+    {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
+        if (lane == 0 && m) atomicAdd(f.hit_count, m);
+    }
+
+    v3 result[P], result2[P], nDir[P], tcol[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        result[p] = result2[p] = V3(0.0f, 0.0f, 0.0f);
+        const float *t = f.tris15 + (size_t)15 * (best_i[p] >= 0 ? best_i[p] : 0);
+        nDir[p] = normalize3(ld3(t + 9));                                    // :300
+        tcol[p] = ld3(t + 12);
+    }
+    if (__any(any_hit)) {
+        for (int k = 0; k < f.nlights; k++) {
+            const v3 L = ld3(f.lpos[k]);
+            const float4 *tab = s_light + (size_t)3 * n * k;
+            v3 D[P], rd[P];
+            float thr[P];
+            bool live[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                float r;
+                D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
+                thr[p] = r * 0.99f;                                          // :313
+                live[p] = hit[p];
+            }
+#pragma unroll 2
+            for (int j = 0; j < n; j++) {
+                const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const TestDots d = test_dots(r0, r1, r2, rd[p]);         // negD = rDir (:310, :229)
+                    if (live[p] && (!FILTER || maybe_hit(d))) {
+                        v3 hp;
+                        float dist;
+                        if (exact_hit_lds(d, r0.w, s_geo + 3 * j, L, &hp, &dist))
+                            if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);   // :313-314
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                result[p] = add3(result[p], D[p]);                           // :319
+                result2[p] = add3(result2[p], result[p]);                    // :322
+            }
+        }
+    }
+
+    const v3 N = ld3(f.indirect);
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        if (!ok[p]) continue;
+        v3 avg = V3(0.0f, 0.0f, 0.0f);
+        if (hit[p]) {
+            const v3 Dl = mul3(result2[p], tcol[p]);                         // :325-326
+            const v3 T = add3(Dl, N);                                        // :584-586
+            avg = add3(avg, mul3(tcol[p], T));                               // :587-591
+        }
+        avg = div3s(avg, 1.0f);                                              // :599
+        const int x = xs[p];
+        const size_t px = (size_t)y * f.W + x;
+        if (f.rgb) st3(f.rgb + 3 * px, avg);
+        if (f.index) f.index[px] = best_i[p];
+        if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)                  // :618-620
+            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+    }
+}
+
+// `host_unsafe` != 0: operands outside the filter's proven range (decided on the host) -> exact-only path.
+template <int P>
+__global__ __launch_bounds__(256) void k_rt_small(const RtFrame f, int host_unsafe)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_all[];
+    const int n = f.n;
+    // all LDS comes from the dynamic region (a static __shared__ in front would knock the b128 reads off
+    // their 16-byte alignment): [0] = flag word, then the tables
+    int *s_unsafe = reinterpret_cast<int *>(s_all);
+    float4 *s_cam = s_all + 1;                   // n rows
+    float4 *s_geo = s_cam + 3 * n;               // n rows
+    float4 *s_light = s_cam + 6 * n;             // nlights x n rows
+    if (threadIdx.x == 0) *s_unsafe = host_unsafe;
+    __syncthreads();
+    bool bad = false;
+    for (int i = threadIdx.x; i < n * (2 + f.nlights); i += 256) {
+        const int which = i / n, t = i - which * n;
+        const float *t15 = f.tris15 + (size_t)15 * t;
+        if (which == 1) {
+            const v3 v0 = ld3(t15), e1 = sub3(ld3(t15 + 3), v0), e2 = sub3(ld3(t15 + 6), v0);   // :216-217
+            s_geo[3 * t] = make_float4(v0.x, v0.y, v0.z, e1.x);
+            s_geo[3 * t + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+            s_geo[3 * t + 2] = make_float4(e2.z, 0.0f, 0.0f, 0.0f);
+        } else {
+            const v3 S = (which == 0) ? ld3(f.cam) : ld3(f.lpos[which - 2]);
+            const OriginRow r = make_origin_row(t15, S);
+            float4 *dst = (which == 0) ? s_cam + 3 * t : s_light + 3 * ((size_t)(which - 2) * n + t);
+            dst[0] = r.r0; dst[1] = r.r1; dst[2] = r.r2;
+            bad |= !origin_row_safe(r);
+        }
+    }
+    if (bad) atomicOr(s_unsafe, 1);
+    __syncthreads();
+    if (*s_unsafe == 0)
+        small_body<P, true>(f, s_cam, s_light, s_geo);
+    else
+        small_body<P, false>(f, s_cam, s_light, s_geo);
+}
+
+template __global__ void k_rt_small<1>(const RtFrame, int);
+template __global__ void k_rt_small<2>(const RtFrame, int);
+
 template <int P>
 __global__ __launch_bounds__(256) void k_rt_brute(const RtFrame f)
 {

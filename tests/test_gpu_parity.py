@@ -75,6 +75,52 @@ def test_rt_soup_brute(oracle, n, W, H):
     _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), H / 2.0, W, H, DEFAULT_LIGHT)
 
 
+@pytest.mark.parametrize("n,W,H,s", [(700, 320, 200, 0.15), (5000, 333, 207, 0.08), (20000, 640, 360, 0.05)])
+def test_rt_soup_binned(oracle, n, W, H, s):
+    """Binned mode (screen-tile + light-cube candidate lists) must reproduce brute force bit for bit."""
+    tris = mirt.scene_soup(31 + n, n, s)
+    got, _ = _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), H / 2.0, W, H, DEFAULT_LIGHT, mode=mirt.RT_BINNED)
+    assert got["stats"]["mode_used"] == mirt.RT_BINNED
+
+
+def test_rt_binned_camera_inside_soup_rotated_two_lights(oracle):
+    """Triangles beside and behind the camera and all around both lights (every cube face in use)."""
+    tris = mirt.scene_soup(77, 6000, 0.12)
+    lights = np.array([[0, -0.5, -0.7, 1, 1, 1, 14], [0.4, 0.3, 0.2, 0.6, 0.9, 0.3, 5]], np.float32)
+    _rt_compare(oracle, tris, (0.1, -0.2, -0.3), oracle.rot_from_yaw(0.7, 1.0), 150.0, 400, 300, lights, mode=mirt.RT_BINNED)
+
+
+def test_rt_binned_cornell(oracle):
+    """Large triangles spanning many bins, exact-distance ties on shared edges (tie rule restated order-free)."""
+    got, _ = _rt_compare(oracle, mirt.scene_cornell(), (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 250.0, 500, 500, DEFAULT_LIGHT, mode=mirt.RT_BINNED)
+    assert got["stats"]["mode_used"] == mirt.RT_BINNED
+
+
+def test_rt_binned_band(oracle):
+    """A band that does not start on a tile boundary."""
+    import ctypes as C
+    tris = mirt.scene_soup(5, 3000, 0.1)
+    mirt.scene_upload(tris)
+    W, H = 200, 120
+    view = mirt.make_view((0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 60.0, W, H)
+    full = mirt.raytrace(view, DEFAULT_LIGHT, mode=mirt.RT_BRUTE)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    d = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d), W * H * 4) == 0
+    assert hip.hipMemset(d, 0, W * H * 4) == 0
+    for (y0, y1) in [(0, 45), (45, 83), (83, 120)]:
+        mirt.raytrace_device(view, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_BINNED, y0, y1, 0, d, W * 4)
+    mirt.sync()
+    out = np.zeros((H, W), np.uint32)
+    assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), d, W * H * 4, 2) == 0
+    hip.hipFree(d)
+    assert np.array_equal(out, full["xrgb"])
+
+
 def test_rt_miss_everywhere(oracle):
     """Camera looking away: no hit anywhere -> index -1, black, zero shadow rays."""
     tris = mirt.scene_cornell()
