@@ -18,10 +18,7 @@ namespace mirt {
 __global__ void k_prep_origin(const float *, int, const float *, OriginRow *, OriginRow *, uint32_t *);
 template <int P> __global__ void k_rt_brute(const RtFrame);
 template <int P> __global__ void k_rt_small(const RtFrame, int);
-__global__ void k_bin_l0(const OriginRow *, const OriginRow *, int, BinSet, BinQueues);
-__global__ void k_bin_l1(const OriginRow *, const OriginRow *, int, BinSet, BinQueues);
-__global__ void k_bin_l2(const OriginRow *, const OriginRow *, int, BinSet, BinQueues);
-__global__ void k_bin_fill(BinSet, BinQueues);
+template <bool FILL> __global__ void k_bin(const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
     BinSet bins;
@@ -70,7 +67,8 @@ struct Ctx {
     OriginRow *d_light_tab = nullptr;
     int light_tab_lights = 0;
     float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
-    uint32_t *d_flags = nullptr;                 // [0] = unsafe, [2..3] = hit counter (u64)
+    uint32_t *d_flags = nullptr;                 // [0] = unsafe flag
+    unsigned long long *d_hits = nullptr;        // HIT_SHARDS sharded hit counters (rt_common.hpp: count_hits)
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
 
@@ -79,10 +77,8 @@ struct Ctx {
     uint32_t *d_bin_off = nullptr, *d_bin_fill = nullptr, *d_bin_sums = nullptr, *d_bin_counters = nullptr;
     uint32_t *d_entries = nullptr;
     uint32_t cap_bins = 0, cap_entries = 0;
-    unsigned long long *d_q1 = nullptr, *d_q2 = nullptr, *d_q2mask = nullptr;
-    uint32_t *d_qcounters = nullptr;
-    uint32_t cap_q1 = 0, cap_q2 = 0;
     uint64_t bin_key = 0;
+    uint32_t bin_entries = 0;                    // candidate-list entries of the current binning
     bool bin_key_valid = false;
 
     // staging for the host-buffer entry points
@@ -216,7 +212,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     f.pitch_words = pitch_bytes / 4;
     f.rgb = static_cast<float *>(d_rgb);
     f.index = static_cast<int32_t *>(d_index);
-    f.hit_count = reinterpret_cast<unsigned long long *>(g.d_flags + 2);
+    f.hit_count = g.d_hits;
 
     // The pre-reject filter is proven for finite, moderate operands only (rt_common.hpp); anything else
     // (absurd coordinates, NaN/Inf) renders through the exact-only path.  Ray directions of the primary
@@ -239,7 +235,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     // workgroup itself -- no origin-table kernel, no global loads inside the loops.
     const size_t small_lds = 16 + (size_t)g.n * sizeof(OriginRow) * (2 + nlights);
     if (!binned && small_lds <= 48 * 1024) {
-        HIP_TRY(hipMemsetAsync(g.d_flags, 0, 16, g.stream));
+        HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
         k_begin(MIRT_K_TRACE);
         if (P == 2)
             hipLaunchKernelGGL(k_rt_small<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), small_lds, g.stream, f, safe ? 0 : 1);
@@ -252,6 +248,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     }
 
     HIP_TRY(hipMemcpyAsync(g.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
     HIP_TRY(hipMemcpyAsync(g.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
 
     k_begin(MIRT_K_PREP);
@@ -334,26 +331,14 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     }
     HIP_TRY(hipMemcpyAsync(g.d_frames, frames, sizeof(BinFrameDesc) * nframes, hipMemcpyHostToDevice, g.stream));
 
-    // work queues of the hierarchical binner: queue 1 can never hold more than one item per level-0 thread
-    BinQueues q;
-    memset(&q, 0, sizeof q);
+    BinGridInfo gi;
     const int L0 = BIN_COARSE * BIN_COARSE;
-    q.cam_cells_x = (uint32_t)((frames[0].nbu + L0 - 1) / L0);
-    q.cam_cell_y0 = (uint32_t)(frames[0].j0 / L0);
-    q.cam_cells = q.cam_cells_x * (uint32_t)((frames[0].j1 + L0 - 1) / L0 - frames[0].j0 / L0);
-    q.cells_per_tri = q.cam_cells + (uint32_t)(nframes - 1);
-    const size_t need_q1 = (size_t)g.n * q.cells_per_tri;
-    if (need_q1 > g.cap_q1) {
-        if ((rc = dev_realloc(&g.d_q1, need_q1))) { g.cap_q1 = 0; return rc; }
-        g.cap_q1 = (uint32_t)need_q1;
-    }
-    if (!g.d_q2) {
-        const size_t cap = (size_t)1 << 20;
-        if ((rc = dev_realloc(&g.d_q2, cap))) return rc;
-        if ((rc = dev_realloc(&g.d_q2mask, cap))) return rc;
-        g.cap_q2 = (uint32_t)cap;
-    }
-    if (!g.d_qcounters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_qcounters), 16));
+    gi.cam_cells_x = (uint32_t)((frames[0].nbu + L0 - 1) / L0);
+    gi.cam_cell_y0 = (uint32_t)(frames[0].j0 / L0);
+    gi.cam_cells = gi.cam_cells_x * (uint32_t)((frames[0].j1 + L0 - 1) / L0 - frames[0].j0 / L0);
+    gi.cells_per_tri = gi.cam_cells + (uint32_t)(nframes - 1);
+    const size_t bin_threads = (size_t)g.n * gi.cells_per_tri;
+    const unsigned bin_blocks = (unsigned)((bin_threads + 255) / 256);
 
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
     {
@@ -362,51 +347,31 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     }
 
     BinSet bs;
+    bs.frames = g.d_frames; bs.nframes = nframes; bs.nbins = nbins;
+    bs.bin_off = g.d_bin_off; bs.bin_fill = g.d_bin_fill; bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
+    bs.counters = g.d_bin_counters;
     k_begin(MIRT_K_BIN);
-    for (int attempt = 0;; attempt++) {
-        bs.frames = g.d_frames; bs.nframes = nframes; bs.nbins = nbins;
-        bs.bin_off = g.d_bin_off; bs.bin_fill = g.d_bin_fill; bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
-        bs.counters = g.d_bin_counters;
-        q.q1 = g.d_q1; q.q2 = g.d_q2; q.q2mask = g.d_q2mask; q.cap1 = g.cap_q1; q.cap2 = g.cap_q2; q.counters = g.d_qcounters;
-
-        HIP_TRY(hipMemsetAsync(g.d_bin_off, 0, sizeof(uint32_t) * ((size_t)nbins + 1), g.stream));
-        HIP_TRY(hipMemsetAsync(g.d_bin_fill, 0, sizeof(uint32_t) * (size_t)nbins, g.stream));
-        HIP_TRY(hipMemsetAsync(g.d_qcounters, 0, 16, g.stream));
-        const unsigned l0_threads_blocks = (unsigned)((need_q1 + 255) / 256);
-        hipLaunchKernelGGL(k_bin_l0, dim3(l0_threads_blocks), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, q);
-        hipLaunchKernelGGL(k_bin_l1, dim3(2048), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, q);
-        hipLaunchKernelGGL(k_bin_l2, dim3(2048), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, q);
-        enqueue_exclusive_scan(g.d_bin_off, (int)nbins, g.d_bin_sums, g.d_bin_counters, g.stream);
-
-        // Queue 2 and the entry table are sized from counts only the device knows; they are read back (two tiny
-        // copies + one sync) only when the inputs that determine them changed since the last frame.
-        if (!g.bin_key_valid || g.bin_key != key) {
-            uint32_t qc[4] = { 0, 0, 0, 0 }, total = 0;
-            HIP_TRY(hipMemcpyAsync(qc, g.d_qcounters, 16, hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipMemcpyAsync(&total, g.d_bin_counters, 4, hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
-            bool redo = false;
-            if (qc[1] > g.cap_q2) {
-                const size_t cap = (size_t)qc[1] + qc[1] / 8 + 4096;
-                if ((rc = dev_realloc(&g.d_q2, cap))) { g.cap_q2 = 0; return rc; }
-                if ((rc = dev_realloc(&g.d_q2mask, cap))) { g.cap_q2 = 0; return rc; }
-                g.cap_q2 = (uint32_t)cap;
-                redo = true;                       // level 2 ran on a truncated queue: counts are incomplete
-            }
-            if (!redo && total > g.cap_entries) {
-                const size_t cap = (size_t)total + total / 8 + 4096;
-                if ((rc = dev_realloc(&g.d_entries, cap))) { g.cap_entries = 0; return rc; }
-                g.cap_entries = (uint32_t)cap;
-                bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
-            }
-            if (redo && attempt < 3) continue;
-            if (redo) return fail(MIRT_ERR_OUT_OF_MEMORY, "binning queues did not converge");
-            g.bin_key = key;
-            g.bin_key_valid = true;
+    HIP_TRY(hipMemsetAsync(g.d_bin_off, 0, sizeof(uint32_t) * ((size_t)nbins + 1), g.stream));
+    HIP_TRY(hipMemsetAsync(g.d_bin_fill, 0, sizeof(uint32_t) * (size_t)nbins, g.stream));
+    hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
+    enqueue_exclusive_scan(g.d_bin_off, (int)nbins, g.d_bin_sums, g.d_bin_counters, g.stream);
+    // The entry table is sized from a count only the device knows; it is read back (4 bytes + one sync) only
+    // when the inputs that determine it changed since the last frame.
+    if (!g.bin_key_valid || g.bin_key != key) {
+        uint32_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&total, g.d_bin_counters, 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if (total > g.cap_entries) {
+            const size_t cap = (size_t)total + total / 8 + 4096;
+            if ((rc = dev_realloc(&g.d_entries, cap))) { g.cap_entries = 0; return rc; }
+            g.cap_entries = (uint32_t)cap;
+            bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
         }
-        hipLaunchKernelGGL(k_bin_fill, dim3(2048), dim3(256), 0, g.stream, bs, q);
-        break;
+        g.bin_entries = total;
+        g.bin_key = key;
+        g.bin_key_valid = true;
     }
+    hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
     k_end(MIRT_K_BIN);
 
     bf.f = f;
@@ -463,6 +428,7 @@ extern "C" int mirt_init(int device)
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_flags), 16));
     HIP_TRY(hipMemset(g.d_flags, 0, 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
     g.device = device;
     g.init = true;
     return MIRT_OK;
@@ -474,9 +440,8 @@ extern "C" void mirt_shutdown(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
-                     (void *)g.d_flags, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
-                     (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries,
-                     (void *)g.d_q1, (void *)g.d_q2, (void *)g.d_q2mask, (void *)g.d_qcounters })
+                     (void *)g.d_flags, (void *)g.d_hits, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
+                     (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
@@ -665,8 +630,10 @@ extern "C" int mirt_get_stats(mirt_stats *out)
                 g.stats.kernel_ms[k] = ms;
         }
         if (g.pending_is_rt) {
+            static unsigned long long shard[HIT_SHARDS * HIT_SHARD_STRIDE];
+            HIP_TRY(hipMemcpy(shard, g.d_hits, sizeof shard, hipMemcpyDeviceToHost));
             unsigned long long hits = 0;
-            HIP_TRY(hipMemcpy(&hits, g.d_flags + 2, 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < HIT_SHARDS; i++) hits += shard[i * HIT_SHARD_STRIDE];
             g.stats.primary_rays = g.pending_primary;
             g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
             if (g.stats.mode_used == MIRT_RT_BRUTE)

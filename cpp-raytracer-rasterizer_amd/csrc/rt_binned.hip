@@ -6,26 +6,23 @@
 
 namespace mirt {
 
-// ---- hierarchical binning: three uniform levels, a work queue between them -----------------------------
+// ---- hierarchical binning: three levels of the same conservative rectangle test, one kernel -----------
 //
-//   level 0  one THREAD per (triangle, frame, 64x64-bin cell): one rectangle test; survivors -> queue 1
-//   level 1  one WAVE per queue-1 item, lane = one of the cell's 8x8 coarse cells (8x8 bins each) -> queue 2
-//   level 2  one WAVE per queue-2 item, lane = one of the coarse cell's 64 bins: count per bin, and keep the
-//            wave's 64-bit pass mask so the fill pass (after the scan) replays it without re-testing
-// Every level runs the same conservative rect_may_hit(); all lanes of a wave do the same amount of work, so
-// there is no divergence however uneven the triangle sizes are.  Queue items are packed
-//   tri(32) | frame(8) | cell_x(12) | cell_y(12).
+//   level 0  one THREAD per (triangle, frame, 64x64-bin cell): one rectangle test
+//   level 1  the wave then takes its surviving lanes one at a time (ballot loop, edge functions broadcast with
+//            v_readlane): lane = one of the cell's 8x8 coarse cells (8x8 bins each)
+//   level 2  for every surviving coarse cell: lane = one of its 64 bins -> count (pass 1) or fill (pass 2)
+// All 64 lanes always work on the same item, so triangle size does not cause divergence, and no work queue
+// (hence no contended queue counter) is needed.  COUNT and FILL run the identical tests, so the fill pass
+// finds exactly the slots the count pass reserved.
 constexpr int BIN_L0 = BIN_COARSE * BIN_COARSE;       // 64 bins per level-0 cell side
 
-__device__ __forceinline__ unsigned long long pack_item(uint32_t tri, uint32_t frame, uint32_t cx, uint32_t cy)
+__device__ __forceinline__ float bcast(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+__device__ __forceinline__ EdgeFn bcast(const EdgeFn &e, int lane)
 {
-    return ((unsigned long long)tri << 32) | ((unsigned long long)frame << 24) | ((unsigned long long)cx << 12) | cy;
-}
-
-__device__ __forceinline__ const OriginRow &row_of(const BinFrameDesc &fr, const OriginRow *cam_tab, const OriginRow *light_tab,
-                                                   int n, uint32_t tri)
-{
-    return (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
+    EdgeFn r;
+    r.c0 = bcast(e.c0, lane); r.cu = bcast(e.cu, lane); r.cv = bcast(e.cv, lane); r.m = bcast(e.m, lane);
+    return r;
 }
 
 // rectangle of bins [i0,i1) x [j0,j1) in the frame's (u,v) parameters
@@ -36,94 +33,68 @@ __device__ __forceinline__ bool bins_may_hit(const TriBinFns &t, const BinFrameD
     return rect_may_hit(t, u0, u1, v0, v1);
 }
 
-__global__ __launch_bounds__(256) void k_bin_l0(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
-                                                int n, BinSet bs, BinQueues q)
-{
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t tri = id / q.cells_per_tri;
-    if (tri >= (uint32_t)n) return;
-    // which (frame, level-0 cell) this thread owns: frame 0 has cam_cells cells, every other frame exactly one
-    const uint32_t c = id - tri * q.cells_per_tri;
-    uint32_t frame, cx, cy;
-    if (c < q.cam_cells) { frame = 0; cx = c % q.cam_cells_x; cy = q.cam_cell_y0 + c / q.cam_cells_x; }
-    else { frame = 1 + (c - q.cam_cells); cx = 0; cy = 0; }
-    const BinFrameDesc &fr = bs.frames[frame];
-    const TriBinFns t = make_bin_fns(row_of(fr, cam_tab, light_tab, n, tri), fr);
-    const int i0 = cx * BIN_L0, i1 = min((int)(cx + 1) * BIN_L0, fr.nbu);
-    const int j0 = max((int)cy * BIN_L0, fr.j0), j1 = min((int)(cy + 1) * BIN_L0, fr.j1);
-    if (j1 <= j0 || !bins_may_hit(t, fr, i0, i1, j0, j1)) return;
-    const uint32_t slot = atomicAdd(&q.counters[0], 1u);
-    if (slot < q.cap1) q.q1[slot] = pack_item(tri, frame, cx, cy);
-    else atomicExch(&q.counters[3], 1u);
-}
-
-__global__ __launch_bounds__(256) void k_bin_l1(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
-                                                int n, BinSet bs, BinQueues q)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
+                                             int n, BinSet bs, BinGridInfo gi)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t count = min(q.counters[0], q.cap1);
-    for (uint32_t it = wave_id; it < count; it += nwaves) {
-        const unsigned long long item = q.q1[it];
-        const uint32_t tri = (uint32_t)(item >> 32), frame = (uint32_t)(item >> 24) & 0xffu;
-        const uint32_t cx = (uint32_t)(item >> 12) & 0xfffu, cy = (uint32_t)item & 0xfffu;
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tri = id / gi.cells_per_tri;
+    // which (frame, level-0 cell) this thread owns: frame 0 has cam_cells cells, every other frame exactly one
+    const uint32_t c = id - tri * gi.cells_per_tri;
+    uint32_t frame, cx, cy;
+    if (c < gi.cam_cells) { frame = 0; cx = c % gi.cam_cells_x; cy = gi.cam_cell_y0 + c / gi.cam_cells_x; }
+    else { frame = 1 + (c - gi.cam_cells); cx = 0; cy = 0; }
+    bool pass0 = false;
+    TriBinFns t;
+    memset(&t, 0, sizeof t);
+    if (tri < (uint32_t)n) {
         const BinFrameDesc &fr = bs.frames[frame];
-        const TriBinFns t = make_bin_fns(row_of(fr, cam_tab, light_tab, n, tri), fr);
-        const uint32_t ccx = cx * BIN_COARSE + (lane & 7), ccy = cy * BIN_COARSE + (lane >> 3);   // coarse cell
-        const int i0 = ccx * BIN_COARSE, i1 = min((int)(ccx + 1) * BIN_COARSE, fr.nbu);
-        const int j0 = max((int)ccy * BIN_COARSE, fr.j0), j1 = min((int)(ccy + 1) * BIN_COARSE, fr.j1);
-        const bool pass = i0 < fr.nbu && j1 > j0 && bins_may_hit(t, fr, i0, i1, j0, j1);
-        const unsigned long long m = __ballot(pass);
-        if (m == 0ull) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&q.counters[1], (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (pass) {
-            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (slot < q.cap2) q.q2[slot] = pack_item(tri, frame, ccx, ccy);
-            else atomicExch(&q.counters[3], 1u);
+        const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
+        t = make_bin_fns(row, fr);
+        const int i0 = cx * BIN_L0, i1 = min((int)(cx + 1) * BIN_L0, fr.nbu);
+        const int j0 = max((int)cy * BIN_L0, fr.j0), j1 = min((int)(cy + 1) * BIN_L0, fr.j1);
+        pass0 = j1 > j0 && bins_may_hit(t, fr, i0, i1, j0, j1);
+    }
+    unsigned long long m0 = __ballot(pass0);
+    while (m0) {
+        const int src = __builtin_ctzll(m0);
+        m0 &= m0 - 1ull;
+        // the surviving lane's item, made wave-uniform
+        TriBinFns u;
+        u.n = bcast(t.n, src); u.p = bcast(t.p, src); u.q = bcast(t.q, src); u.s = bcast(t.s, src); u.nb = bcast(t.nb, src);
+        const uint32_t utri = (uint32_t)__builtin_amdgcn_readlane((int)tri, src);
+        const uint32_t ufr = (uint32_t)__builtin_amdgcn_readlane((int)frame, src);
+        const uint32_t ucx = (uint32_t)__builtin_amdgcn_readlane((int)cx, src), ucy = (uint32_t)__builtin_amdgcn_readlane((int)cy, src);
+        const BinFrameDesc &fr = bs.frames[ufr];
+        // level 1: lane = coarse cell (8x8 bins) inside the level-0 cell
+        const uint32_t ccx = ucx * BIN_COARSE + (lane & 7), ccy = ucy * BIN_COARSE + (lane >> 3);
+        const int ci0 = ccx * BIN_COARSE, ci1 = min((int)(ccx + 1) * BIN_COARSE, fr.nbu);
+        const int cj0 = max((int)ccy * BIN_COARSE, fr.j0), cj1 = min((int)(ccy + 1) * BIN_COARSE, fr.j1);
+        const bool pass1 = ci0 < fr.nbu && cj1 > cj0 && bins_may_hit(u, fr, ci0, ci1, cj0, cj1);
+        unsigned long long m1 = __ballot(pass1);
+        while (m1) {
+            const int cl = __builtin_ctzll(m1);
+            m1 &= m1 - 1ull;
+            // level 2: lane = bin inside coarse cell `cl`
+            const int i = (int)(ucx * BIN_COARSE + (cl & 7)) * BIN_COARSE + (lane & 7);
+            const int j = (int)(ucy * BIN_COARSE + (cl >> 3)) * BIN_COARSE + (lane >> 3);
+            if (i < fr.nbu && j >= fr.j0 && j < fr.j1 && bins_may_hit(u, fr, i, i + 1, j, j + 1)) {
+                const uint32_t bin = fr.base + (uint32_t)j * fr.nbu + i;
+                if (!FILL) {
+                    atomicAdd(&bs.bin_off[bin], 1u);                 // counts, scanned in place afterwards
+                } else {
+                    const uint32_t slot = bs.bin_off[bin] + atomicAdd(&bs.bin_fill[bin], 1u);
+                    if (slot < bs.cap_entries) bs.entries[slot] = utri;
+                    else atomicExch(&bs.counters[1], 1u);
+                }
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_bin_l2(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
-                                                int n, BinSet bs, BinQueues q)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t count = min(q.counters[1], q.cap2);
-    for (uint32_t it = wave_id; it < count; it += nwaves) {
-        const unsigned long long item = q.q2[it];
-        const uint32_t tri = (uint32_t)(item >> 32), frame = (uint32_t)(item >> 24) & 0xffu;
-        const uint32_t ccx = (uint32_t)(item >> 12) & 0xfffu, ccy = (uint32_t)item & 0xfffu;
-        const BinFrameDesc &fr = bs.frames[frame];
-        const TriBinFns t = make_bin_fns(row_of(fr, cam_tab, light_tab, n, tri), fr);
-        const int i = ccx * BIN_COARSE + (lane & 7), j = ccy * BIN_COARSE + (lane >> 3);
-        const bool pass = i < fr.nbu && j >= fr.j0 && j < fr.j1 && bins_may_hit(t, fr, i, i + 1, j, j + 1);
-        if (pass) atomicAdd(&bs.bin_off[fr.base + (uint32_t)j * fr.nbu + i], 1u);     // counts, scanned in place afterwards
-        const unsigned long long m = __ballot(pass);
-        if (lane == 0) q.q2mask[it] = m;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_bin_fill(BinSet bs, BinQueues q)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t count = min(q.counters[1], q.cap2);
-    for (uint32_t it = wave_id; it < count; it += nwaves) {
-        const unsigned long long m = q.q2mask[it];
-        if (!((m >> lane) & 1ull)) continue;
-        const unsigned long long item = q.q2[it];
-        const uint32_t tri = (uint32_t)(item >> 32), frame = (uint32_t)(item >> 24) & 0xffu;
-        const uint32_t ccx = (uint32_t)(item >> 12) & 0xfffu, ccy = (uint32_t)item & 0xfffu;
-        const BinFrameDesc &fr = bs.frames[frame];
-        const uint32_t bin = fr.base + (ccy * BIN_COARSE + (lane >> 3)) * fr.nbu + ccx * BIN_COARSE + (lane & 7);
-        const uint32_t slot = bs.bin_off[bin] + atomicAdd(&bs.bin_fill[bin], 1u);
-        if (slot < bs.cap_entries) bs.entries[slot] = tri;
-        else atomicExch(&bs.counters[1], 1u);
-    }
-}
+template __global__ void k_bin<false>(const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
+template __global__ void k_bin<true>(const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 
 // ---- k_rt_binned: fused primary + shadow + shade + resolve over the binned candidates ---------------
 //
@@ -185,8 +156,11 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float4 n0 = s_rows[wave][0], n1 = s_rows[wave][1], n2 = s_rows[wave][2];
             for (int j = 0; j < cnt; j++) {
-                const float4 r0 = s_rows[wave][3 * j], r1 = s_rows[wave][3 * j + 1], r2 = s_rows[wave][3 * j + 2];
+                const float4 r0 = n0, r1 = n1, r2 = n2;   // software pipeline: row j+1 loads while row j is tested
+                const int jn = min(j + 1, cnt - 1);
+                n0 = s_rows[wave][3 * jn]; n1 = s_rows[wave][3 * jn + 1]; n2 = s_rows[wave][3 * jn + 2];
                 const TestDots td = test_dots(r0, r1, r2, nd);
                 if (maybe_hit(td)) {
                     const int idx = (int)s_idx[wave][j];
@@ -205,7 +179,7 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
     const bool hit = ok && best_i >= 0;
     {
         const unsigned long long m = __popcll(__ballot(hit));
-        if (lane == 0 && m) atomicAdd(f.hit_count, m);
+        count_hits(f, m);
     }
     if (!ok) return;
 

@@ -53,12 +53,8 @@ struct BinSet {
     uint32_t *counters;           // [0] total entries, [1] overflow flag
 };
 
-// Work queues of the hierarchical binner (rt_binned.hip).  counters: [0] queue-1 items, [1] queue-2 items,
-// [3] overflow flag.
-struct BinQueues {
-    unsigned long long *q1, *q2, *q2mask;
-    uint32_t cap1, cap2;
-    uint32_t *counters;
+// How the level-0 cells of all frames are numbered per triangle (rt_binned.hip: k_bin).
+struct BinGridInfo {
     uint32_t cells_per_tri;      // level-0 cells per triangle over all frames
     uint32_t cam_cells, cam_cells_x, cam_cell_y0;
 };

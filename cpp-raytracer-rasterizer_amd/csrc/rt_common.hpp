@@ -118,8 +118,23 @@ struct RtFrame {
     int pitch_words;
     float *rgb;                 // nullable, stride W
     int32_t *index;             // nullable, stride W
-    unsigned long long *hit_count;
+    unsigned long long *hit_count;   // HIT_SHARDS counters, HIT_SHARD_STRIDE u64 apart (see count_hits)
 };
+
+// Every wave reports how many of its primary rays hit (the shadow-ray count of the frame).  One counter for the
+// whole grid serialises ~30k atomics on one address (measured: ~7 ns each, i.e. the entire kernel time of a
+// Cornell-box frame), so the count is spread over HIT_SHARDS addresses on separate 128-byte lines and summed
+// on the host in mirt_get_stats().
+constexpr int HIT_SHARDS = 256;
+constexpr int HIT_SHARD_STRIDE = 16;
+
+__device__ __forceinline__ void count_hits(const RtFrame &f, unsigned long long wave_hits)
+{
+    if ((threadIdx.x & 63) == 0 && wave_hits) {
+        const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x + (threadIdx.x >> 6) * 61u) % HIT_SHARDS;
+        atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE, wave_hits);
+    }
+}
 
 // Per-light shading term D of DirectLight (raytracer.cpp:294-304) before the shadow test.
 __device__ __forceinline__ v3 light_term(const RtFrame &f, int k, v3 hit, v3 nDir, v3 *rDir, float *r)

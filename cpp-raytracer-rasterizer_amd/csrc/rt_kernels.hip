@@ -73,9 +73,11 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
             for (int k = threadIdx.x; k < cnt * 3; k += 256) s_tab[k] = src[k];
         }
         __syncthreads();
-#pragma unroll 2
+        float4 n0 = s_tab[0], n1 = s_tab[1], n2 = s_tab[2];
         for (int j = 0; j < cnt; j++) {
-            const float4 r0 = s_tab[3 * j], r1 = s_tab[3 * j + 1], r2 = s_tab[3 * j + 2];
+            const float4 r0 = n0, r1 = n1, r2 = n2;       // software pipeline: row j+1 loads while row j is tested
+            const int jn = min(j + 1, cnt - 1);
+            n0 = s_tab[3 * jn]; n1 = s_tab[3 * jn + 1]; n2 = s_tab[3 * jn + 2];
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const TestDots d = test_dots(r0, r1, r2, nd[p]);
@@ -105,7 +107,7 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
         unsigned long long m = 0;
 #pragma unroll
         for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
-        if (lane == 0 && m) atomicAdd(f.hit_count, m);
+        count_hits(f, m);
     }
 
     for (int k = 0; k < f.nlights; k++) {
@@ -134,9 +136,11 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
             }
             __syncthreads();
             if (!__any(any_live)) continue;
-#pragma unroll 2
+            float4 n0 = s_tab[0], n1 = s_tab[1], n2 = s_tab[2];
             for (int j = 0; j < cnt; j++) {
-                const float4 r0 = s_tab[3 * j], r1 = s_tab[3 * j + 1], r2 = s_tab[3 * j + 2];
+                const float4 r0 = n0, r1 = n1, r2 = n2;
+                const int jn = min(j + 1, cnt - 1);
+                n0 = s_tab[3 * jn]; n1 = s_tab[3 * jn + 1]; n2 = s_tab[3 * jn + 2];
 #pragma unroll
                 for (int p = 0; p < P; p++) {
                     // shadow ray: start = light, dir = -rDir, so negD = rDir (:310, :229)
@@ -232,9 +236,12 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
         best_i[p] = -1;
         pos[p] = V3(0.0f, 0.0f, 0.0f);
     }
-#pragma unroll 2
+    // software pipeline: row j+1 is on its way from LDS while row j is tested
+    float4 n0 = s_cam[0], n1 = s_cam[1], n2 = s_cam[2];
     for (int j = 0; j < n; j++) {
-        const float4 r0 = s_cam[3 * j], r1 = s_cam[3 * j + 1], r2 = s_cam[3 * j + 2];
+        const float4 r0 = n0, r1 = n1, r2 = n2;
+        const int jn = min(j + 1, n - 1);
+        n0 = s_cam[3 * jn]; n1 = s_cam[3 * jn + 1]; n2 = s_cam[3 * jn + 2];
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const TestDots d = test_dots(r0, r1, r2, nd[p]);
@@ -255,7 +262,7 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
         unsigned long long m = 0;
 #pragma unroll
         for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
-        if (lane == 0 && m) atomicAdd(f.hit_count, m);
+        count_hits(f, m);
     }
 
     v3 result[P], result2[P], nDir[P], tcol[P];
@@ -280,9 +287,11 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
                 thr[p] = r * 0.99f;                                          // :313
                 live[p] = hit[p];
             }
-#pragma unroll 2
+            float4 n0 = tab[0], n1 = tab[1], n2 = tab[2];
             for (int j = 0; j < n; j++) {
-                const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
+                const float4 r0 = n0, r1 = n1, r2 = n2;
+                const int jn = min(j + 1, n - 1);
+                n0 = tab[3 * jn]; n1 = tab[3 * jn + 1]; n2 = tab[3 * jn + 2];
 #pragma unroll
                 for (int p = 0; p < P; p++) {
                     const TestDots d = test_dots(r0, r1, r2, rd[p]);         // negD = rDir (:310, :229)

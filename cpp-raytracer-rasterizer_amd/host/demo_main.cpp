@@ -1,0 +1,59 @@
+// demo_main.cpp -- the reference's main() loops (raytracer.cpp:113-178, rasteriser.cpp:101-149) on top of
+// mirt_draw.hpp, without SDL: a heap surface stands in for the window, one Update()+Draw() per "loop".
+//   demo_main rt|raster [width height [out.bmp [out.xrgb]]]
+// Writes a BMP screenshot (what SDL_SaveBMP(screen, "screenshot.bmp") does at :175/:147) and, optionally, the
+// raw XRGB words so tests can compare them with the oracle.
+#include "mirt_draw.hpp"
+
+#include <cstdlib>
+#include <iostream>
+
+using namespace mirt_host;
+
+int main(int argc, char **argv)
+{
+    const std::string which = argc > 1 ? argv[1] : "rt";
+    const int W = argc > 3 ? std::atoi(argv[2]) : 500, H = argc > 3 ? std::atoi(argv[3]) : 500;
+    const char *bmp = argc > 4 ? argv[4] : "screenshot.bmp";
+    const char *raw = argc > 5 ? argv[5] : nullptr;
+    try {
+        check(mirt_init(0), "mirt_init");
+        std::vector<uint32_t> pixels((size_t)W * H, 0u);
+        Surface screen = { pixels.data(), W, H, W * 4 };            // InitializeSDL(W, H): 32-bit SWSURFACE
+        if (which == "rt") {
+            RayTracer app;
+            app.SCREEN_WIDTH = W; app.SCREEN_HEIGHT = H;
+            app.focalLength = (float)H / 2.0f;                       // 250 for the reference's 500x500
+            app.screen = screen;
+            app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // raytracer.cpp:116
+            app.LoadTestModel();                                     // :149
+            app.cameraRot[1][1] = 1.0f;                              // :162
+            for (int loop = 0; loop < 2; loop++) {                   // while (NoQuitMessageSDL())
+                app.Update();
+                if (app.isUpdated) { app.Draw(); app.isUpdated = false; }
+            }
+        } else {
+            Rasteriser app;
+            app.SCREEN_WIDTH = W; app.SCREEN_HEIGHT = H;
+            app.focalLength = (float)H;                              // 500 for the reference's 500x500
+            app.screen = screen;
+            app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // rasteriser.cpp:104
+            app.LoadTestModel();                                     // :112
+            app.cameraRot[1][1] = 1.01f;                             // :115 (sic)
+            for (int loop = 0; loop < 2; loop++) {
+                app.Update();
+                if (app.isUpdated) { app.Draw(); app.isUpdated = false; }
+            }
+        }
+        mirt_stats st;
+        check(mirt_get_stats(&st), "mirt_get_stats");
+        std::cout << "Render time: " << st.gpu_ms << " ms." << std::endl;   // the reference's only metric (:343)
+        save_bmp(screen, bmp);
+        if (raw) { FILE *f = std::fopen(raw, "wb"); if (f) { std::fwrite(pixels.data(), 4, pixels.size(), f); std::fclose(f); } }
+        mirt_shutdown();
+    } catch (const std::exception &e) {
+        std::cerr << "demo_main: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -64,3 +64,16 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".hip", ".cpp", ".hpp", ".h", ".py")) or f == "Makefile":
                 text = open(os.path.join(dp, f)).read()
                 assert "mirt_oracle" not in text and "oracle/" not in text.replace("the oracle", ""), os.path.join(dp, f)
+
+
+def test_host_adapter_fails_loudly_without_gpu():
+    """The C++ Draw() adapter demo must refuse to run (non-zero exit, clear message) when no GPU is present."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "cpp-raytracer-rasterizer_amd", "host", "demo_main")
+    if not os.path.exists(exe):
+        pytest.skip("host/demo_main not built")
+    r = subprocess.run([exe, "rt", "32", "32", "/dev/null"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no HIP device" in r.stderr

@@ -240,3 +240,33 @@ def test_errors_are_reported_not_fatal():
     view = mirt.make_view((0, 0, -2), np.eye(3, dtype=np.float32).ravel(), 10.0, 0, 10)
     with pytest.raises(mirt.MirtError):
         mirt.raytrace(view, DEFAULT_LIGHT)
+
+
+# ---- the C++ host adapter (reference-shaped Draw()) ---------------------------------------------------
+
+@pytest.mark.parametrize("which", ["rt", "raster"])
+def test_host_draw_adapter_matches_oracle(oracle, tmp_path, which):
+    """cpp-raytracer-rasterizer_amd/host/demo_main runs the reference's main loop shape (Update(); Draw();) through
+    mirt_draw.hpp and the C-ABI; its surface must hold exactly the words the oracle's PutPixelSDL path produces."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cpp-raytracer-rasterizer_amd", "host", "demo_main")
+    assert os.path.exists(exe), "host/demo_main not built (make -C cpp-raytracer-rasterizer_amd)"
+    W = H = 200
+    raw, bmp = str(tmp_path / "out.xrgb"), str(tmp_path / "out.bmp")
+    mirt.shutdown()                      # the child process owns the GPU context for this test
+    try:
+        subprocess.run([exe, which, str(W), str(H), bmp, raw], check=True, timeout=300)
+    finally:
+        mirt.init(0)
+    got = np.fromfile(raw, np.uint32).reshape(H, W)
+    tris = oracle.cornell()
+    if which == "rt":
+        ref = oracle.raytrace(tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), H / 2.0, W, H, DEFAULT_LIGHT)["xrgb"]
+    else:
+        rot = oracle.rot_from_yaw(0.0, 1.01)
+        culled = oracle.cull(tris, (0, 0, -3), rot, float(H), W, H, 3)
+        ref = oracle.rasterise(tris, culled, (0, 0, -3), rot, float(H), W, H, DEFAULT_LIGHT)["xrgb"]
+    assert np.array_equal(got, ref)
+    assert os.path.getsize(bmp) == 54 + W * 3 * H
