@@ -632,11 +632,12 @@ extern "C" int mirt_get_stats(mirt_stats *out)
         if (g.pending_is_rt) {
             static unsigned long long shard[HIT_SHARDS * HIT_SHARD_STRIDE];
             HIP_TRY(hipMemcpy(shard, g.d_hits, sizeof shard, hipMemcpyDeviceToHost));
-            unsigned long long hits = 0;
-            for (int i = 0; i < HIT_SHARDS; i++) hits += shard[i * HIT_SHARD_STRIDE];
+            unsigned long long hits = 0, tests = 0;
+            for (int i = 0; i < HIT_SHARDS; i++) { hits += shard[i * HIT_SHARD_STRIDE]; tests += shard[i * HIT_SHARD_STRIDE + 1]; }
+            g.stats.tests = tests;
             g.stats.primary_rays = g.pending_primary;
             g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
-            if (g.stats.mode_used == MIRT_RT_BRUTE)
+            if (g.stats.mode_used == MIRT_RT_BRUTE)       // every ray tests every triangle
                 g.stats.tests = (g.stats.primary_rays + g.stats.shadow_rays) * (uint64_t)g.n;
         }
         g.stats_pending = false;

@@ -138,10 +138,12 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
     float best_d = FLT_MAX;
     int best_i = -1;
     v3 pos = V3(0.0f, 0.0f, 0.0f);
+    unsigned ntests = 0;
 
     if (tile_ok) {
         const uint32_t bin = bf.cam_base + (uint32_t)ty * bf.tiles_x + tx;
         const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
+        if (ok) ntests = end - beg;
         for (uint32_t base = beg; base < end; base += 64) {
             const int cnt = (int)min(64u, end - base);
             if (lane < cnt) {
@@ -181,7 +183,8 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
         const unsigned long long m = __popcll(__ballot(hit));
         count_hits(f, m);
     }
-    if (!ok) return;
+    if (!__any(hit)) count_tests(f, ntests);      // no shadow rays in this wave: report now
+    if (!ok && !__any(hit)) return;
 
     v3 avg = V3(0.0f, 0.0f, 0.0f);
     if (hit) {
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
             const uint32_t bin = cube_bin_of(rd, bf.light_base[k]);
             const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
             const OriginRow *tab = f.light_tab + (size_t)k * f.n;
-            for (uint32_t e = beg; e < end; e++) {
+            uint32_t e = beg;
+            for (; e < end; e++) {
                 const uint32_t idx = bf.bins.entries[e];
                 const float4 *src = reinterpret_cast<const float4 *>(tab + idx);
                 const float4 r0 = src[0], r1 = src[1], r2 = src[2];
@@ -208,10 +212,12 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
                     float dist;
                     if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, L, &hp, &dist) && dist < thr) {
                         D = V3(0.0f, 0.0f, 0.0f);          // occluded (:313-314); any-hit is exact
+                        e++;
                         break;
                     }
                 }
             }
+            ntests += e - beg;
             result = add3(result, D);                      // (:319)
             result2 = add3(result2, result);               // (:322)
         }
@@ -219,6 +225,8 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
         const v3 T = add3(Dl, ld3(f.indirect));            // (:584-586)
         avg = add3(avg, mul3(tcol, T));                    // (:587-591)
     }
+    if (__any(hit)) count_tests(f, ntests);
+    if (!ok) return;
     avg = div3s(avg, 1.0f);                                // (:599)
     const size_t px = (size_t)y * f.W + x;
     if (f.rgb) st3(f.rgb + 3 * px, avg);

@@ -136,6 +136,24 @@ __device__ __forceinline__ void count_hits(const RtFrame &f, unsigned long long 
     }
 }
 
+// 64-lane sum (DPP/ds_swizzle-free shuffle tree); every lane returns the total
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// ray-triangle tests a wave executed (second word of the shard); used for the roofline of the binned path
+__device__ __forceinline__ void count_tests(const RtFrame &f, unsigned lane_tests)
+{
+    const unsigned total = wave_sum(lane_tests);
+    if ((threadIdx.x & 63) == 0 && total) {
+        const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x + (threadIdx.x >> 6) * 61u) % HIT_SHARDS;
+        atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 1, (unsigned long long)total);
+    }
+}
+
 // Per-light shading term D of DirectLight (raytracer.cpp:294-304) before the shadow test.
 __device__ __forceinline__ v3 light_term(const RtFrame &f, int k, v3 hit, v3 nDir, v3 *rDir, float *r)
 {

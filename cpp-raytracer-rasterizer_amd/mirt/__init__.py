@@ -227,4 +227,38 @@ def rasterise_device(view, lights7, indirect, y0, y1, row_origin, d_xrgb, pitch_
                                         d_xrgb, int(pitch_bytes), d_rgb, d_zinv, d_index))
 
 
+def prepared_raytrace_device(view, lights7, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb=None,
+                             d_index=None):
+    """Marshals the arguments once and returns a zero-argument callable that enqueues the frame: keeps the
+    per-frame host cost of a render loop at one foreign call."""
+    lib = load()
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32).copy()
+    args = (C.byref(view), larr, nl, _ptr(ind), int(mode), int(y0), int(y1), int(row_origin), d_xrgb, int(pitch_bytes),
+            d_rgb, d_index)
+    fn = lib.mirt_raytrace_device
+
+    def launch(_keep=(view, larr, ind)):
+        rc = fn(*args)
+        if rc:
+            _check(rc)
+    return launch
+
+
+def prepared_rasterise_device(view, lights7, indirect, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb=None, d_zinv=None,
+                              d_index=None):
+    lib = load()
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32).copy()
+    args = (C.byref(view), larr, nl, _ptr(ind), int(y0), int(y1), int(row_origin), d_xrgb, int(pitch_bytes), d_rgb,
+            d_zinv, d_index)
+    fn = lib.mirt_rasterise_device
+
+    def launch(_keep=(view, larr, ind)):
+        rc = fn(*args)
+        if rc:
+            _check(rc)
+    return launch
+
+
 DEFAULT_LIGHT = np.array([[0.0, -0.5, -0.7, 1.0, 1.0, 1.0, 14.0]], np.float32)

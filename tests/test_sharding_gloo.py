@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: world_size-2 and -3 gloo process groups shard a frame into row bands, every rank renders
+its band (here with the oracle, since there is no GPU), rank 0 gathers them; the assembled frame must be
+byte-identical to the single-process frame.  This is the same BandGather / band_of code bench.py runs over
+RCCL on the GPU box."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, W, H, kind, out_path):
+    for sub in ("oracle", "cpp-raytracer-rasterizer_amd"):
+        sys.path.insert(0, os.path.join(ROOT, sub))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirt.sharding import BandGather
+    from mirt_oracle import Oracle, DEFAULT_LIGHT
+    o = Oracle()
+    tris = o.soup(9, 200, 0.3) if kind == "soup" else o.cornell()
+    g = BandGather(H, W, torch.device("cpu"))
+    rot = o.rot_from_yaw(0.2, 1.0)
+    r = o.raytrace(tris, (0, 0, -2), rot, H / 2.0, W, H, DEFAULT_LIGHT, y0=g.y0, y1=g.y1, threads=2, want=("xrgb",))
+    g.band[: g.y1 - g.y0] = torch.from_numpy(r["xrgb"][g.y0:g.y1].view(np.int32))
+    frame = g.gather()
+    if rank == 0:
+        np.save(out_path, frame.numpy().view(np.uint32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,kind", [(2, 64, "cornell"), (3, 50, "soup"), (2, 31, "soup")])
+def test_band_gather_matches_single_process(tmp_path, oracle, world, H, kind):
+    from mirt_oracle import DEFAULT_LIGHT
+    W = 48
+    out = str(tmp_path / "frame.npy")
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, W, H, kind, out), nprocs=world, join=True)
+    got = np.load(out)
+    tris = oracle.soup(9, 200, 0.3) if kind == "soup" else oracle.cornell()
+    ref = oracle.raytrace(tris, (0, 0, -2), oracle.rot_from_yaw(0.2, 1.0), H / 2.0, W, H, DEFAULT_LIGHT, want=("xrgb",))["xrgb"]
+    assert np.array_equal(got, ref)
+
+
+def test_band_of_partitions_rows():
+    from mirt.sharding import all_bands
+    for H in (1, 7, 540, 1080, 4320):
+        for world in (1, 2, 3, 4, 8):
+            bands = all_bands(world, H)
+            assert bands[0][0] == 0 and bands[-1][1] == H
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in bands]
+            assert max(sizes) - min(sizes) <= 1
