@@ -18,7 +18,7 @@ namespace mirt {
 __global__ void k_prep_origin(const float *, int, const float *, OriginRow *, OriginRow *, uint32_t *);
 template <int P> __global__ void k_rt_brute(const RtFrame);
 template <int P> __global__ void k_rt_small(const RtFrame, int);
-template <bool FILL> __global__ void k_bin(const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
+template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
     BinSet bins;
@@ -114,22 +114,24 @@ int dev_realloc(T **p, size_t count)
 
 int ensure_staging(size_t px, bool rgb, bool index, bool zinv)
 {
+    // All staging planes share ONE capacity (g.cap_px pixels): a plane that is first needed by a small frame must
+    // still be big enough for every frame size the other planes were already grown to.
     if (px > g.cap_px) {
         for (void **p : { &g.d_xrgb, &g.d_rgb, &g.d_index, &g.d_zinv }) { if (*p) (void)hipFree(*p); *p = nullptr; }
-        g.cap_px = 0;
+        g.cap_px = px;
     }
-    auto grow = [&](void **p, size_t bytes) -> int {
+    auto grow = [&](void **p, size_t bytes_per_px) -> int {
         if (*p) return MIRT_OK;
+        const size_t bytes = g.cap_px * bytes_per_px;
         hipError_t e = hipMalloc(p, bytes);
         if (e != hipSuccess) { *p = nullptr; return fail(MIRT_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
         return MIRT_OK;
     };
     int rc;
-    if ((rc = grow(&g.d_xrgb, px * 4))) return rc;
-    if (rgb && (rc = grow(&g.d_rgb, px * 12))) return rc;
-    if (index && (rc = grow(&g.d_index, px * 4))) return rc;
-    if (zinv && (rc = grow(&g.d_zinv, px * 4))) return rc;
-    if (px > g.cap_px) g.cap_px = px;
+    if ((rc = grow(&g.d_xrgb, 4))) return rc;
+    if (rgb && (rc = grow(&g.d_rgb, 12))) return rc;
+    if (index && (rc = grow(&g.d_index, 4))) return rc;
+    if (zinv && (rc = grow(&g.d_zinv, 4))) return rc;
     return MIRT_OK;
 }
 
@@ -288,6 +290,28 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         for (int i = 0; i < 3; i++)
             dm = fmaxf(dm, fabsf(R[0 + i]) * (hw + 1.0f) + fabsf(R[3 + i]) * (hh + 1.0f) + fabsf(R[6 + i]) * fabsf(view->focal));
         c.dmax = dm;
+        // inverse map for the bounding boxes: h = R^-1 (P - S) = lambda * (x - W/2, y - H/2, f), so with g = S - P
+        //   w = -(R^-1 row 2 . g) / f,  u = (-(R^-1 row 0 . g) + (W/2) f w / f ... ) -> rows below; computed in double
+        {
+            double M[9], inv[9];
+            for (int i = 0; i < 9; i++) M[i] = R[i];
+#define MM(cc, rr) M[(cc) * 3 + (rr)]
+            const double det = MM(0, 0) * (MM(1, 1) * MM(2, 2) - MM(2, 1) * MM(1, 2)) - MM(1, 0) * (MM(0, 1) * MM(2, 2) - MM(2, 1) * MM(0, 2)) +
+                               MM(2, 0) * (MM(0, 1) * MM(1, 2) - MM(1, 1) * MM(0, 2));
+            // inv is row-major here: inv[r*3+c] = (R^-1)(r, c)
+            inv[0] = (MM(1, 1) * MM(2, 2) - MM(2, 1) * MM(1, 2)) / det; inv[1] = -(MM(1, 0) * MM(2, 2) - MM(2, 0) * MM(1, 2)) / det; inv[2] = (MM(1, 0) * MM(2, 1) - MM(2, 0) * MM(1, 1)) / det;
+            inv[3] = -(MM(0, 1) * MM(2, 2) - MM(2, 1) * MM(0, 2)) / det; inv[4] = (MM(0, 0) * MM(2, 2) - MM(2, 0) * MM(0, 2)) / det; inv[5] = -(MM(0, 0) * MM(2, 1) - MM(2, 0) * MM(0, 1)) / det;
+            inv[6] = (MM(0, 1) * MM(1, 2) - MM(1, 1) * MM(0, 2)) / det; inv[7] = -(MM(0, 0) * MM(1, 2) - MM(1, 0) * MM(0, 2)) / det; inv[8] = (MM(0, 0) * MM(1, 1) - MM(1, 0) * MM(0, 1)) / det;
+#undef MM
+            const bool ok = std::isfinite(det) && det != 0.0 && view->focal != 0.0f;
+            for (int i = 0; i < 3; i++) {
+                const double rwd = ok ? -inv[6 + i] / (double)view->focal : 0.0;       // w = h.z / f, h = -R^-1 g
+                c.rw[i] = (float)rwd;
+                c.ru[i] = (float)(ok ? -inv[0 + i] + (double)hw * rwd : 0.0);          // u*w = h.x + (W/2) w
+                c.rv[i] = (float)(ok ? -inv[3 + i] + (double)hh * rwd : 0.0);
+            }
+        }
+        memcpy(c.S, view->pos, 12);
         c.ulo = 0.0f; c.vlo = 0.0f; c.du = (float)BIN_TILE; c.dv = (float)BIN_TILE;
         c.pad_lo = 0.0f; c.pad_hi = -1.0f;                // bin i covers pixels 8i .. 8i+7 exactly
         c.nbu = (W + BIN_TILE - 1) / BIN_TILE; c.nbv = (H + BIN_TILE - 1) / BIN_TILE;
@@ -306,6 +330,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             d.P0[ax] = (face & 1) ? -1.0f : 1.0f;         // negD ~ s*e_k + u*e_(k+1) + v*e_(k+2)
             d.Pu[(ax + 1) % 3] = 1.0f;
             d.Pv[(ax + 2) % 3] = 1.0f;
+            d.rw[ax] = d.P0[ax]; d.ru[(ax + 1) % 3] = 1.0f; d.rv[(ax + 2) % 3] = 1.0f;   // g = m*(s e_k + u e_k1 + v e_k2)
+            memcpy(d.S, lights[k].pos, 12);
             d.dmax = 2.0f;
             d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / CUBE_BINS; d.dv = 2.0f / CUBE_BINS;
             d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
@@ -353,7 +379,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     k_begin(MIRT_K_BIN);
     HIP_TRY(hipMemsetAsync(g.d_bin_off, 0, sizeof(uint32_t) * ((size_t)nbins + 1), g.stream));
     HIP_TRY(hipMemsetAsync(g.d_bin_fill, 0, sizeof(uint32_t) * (size_t)nbins, g.stream));
-    hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
+    hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_tris, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
     enqueue_exclusive_scan(g.d_bin_off, (int)nbins, g.d_bin_sums, g.d_bin_counters, g.stream);
     // The entry table is sized from a count only the device knows; it is read back (4 bytes + one sync) only
     // when the inputs that determine it changed since the last frame.
@@ -371,7 +397,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         g.bin_key = key;
         g.bin_key_valid = true;
     }
-    hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
+    hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_tris, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
     k_end(MIRT_K_BIN);
 
     bf.f = f;

@@ -34,8 +34,8 @@ __device__ __forceinline__ bool bins_may_hit(const TriBinFns &t, const BinFrameD
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin(const OriginRow *__restrict__ cam_tab, const OriginRow *__restrict__ light_tab,
-                                             int n, BinSet bs, BinGridInfo gi)
+__global__ __launch_bounds__(256) void k_bin(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
+                                             const OriginRow *__restrict__ light_tab, int n, BinSet bs, BinGridInfo gi)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_bin(const OriginRow *__restrict__ cam_t
         const BinFrameDesc &fr = bs.frames[frame];
         const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
         t = make_bin_fns(row, fr);
+        add_bbox(t, tris15 + (size_t)15 * tri, fr);
         const int i0 = cx * BIN_L0, i1 = min((int)(cx + 1) * BIN_L0, fr.nbu);
         const int j0 = max((int)cy * BIN_L0, fr.j0), j1 = min((int)(cy + 1) * BIN_L0, fr.j1);
         pass0 = j1 > j0 && bins_may_hit(t, fr, i0, i1, j0, j1);
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void k_bin(const OriginRow *__restrict__ cam_t
         // the surviving lane's item, made wave-uniform
         TriBinFns u;
         u.n = bcast(t.n, src); u.p = bcast(t.p, src); u.q = bcast(t.q, src); u.s = bcast(t.s, src); u.nb = bcast(t.nb, src);
+        u.bu0 = bcast(t.bu0, src); u.bu1 = bcast(t.bu1, src); u.bv0 = bcast(t.bv0, src); u.bv1 = bcast(t.bv1, src);
         const uint32_t utri = (uint32_t)__builtin_amdgcn_readlane((int)tri, src);
         const uint32_t ufr = (uint32_t)__builtin_amdgcn_readlane((int)frame, src);
         const uint32_t ucx = (uint32_t)__builtin_amdgcn_readlane((int)cx, src), ucy = (uint32_t)__builtin_amdgcn_readlane((int)cy, src);
@@ -93,8 +95,8 @@ __global__ __launch_bounds__(256) void k_bin(const OriginRow *__restrict__ cam_t
     }
 }
 
-template __global__ void k_bin<false>(const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
-template __global__ void k_bin<true>(const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
+template __global__ void k_bin<false>(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
+template __global__ void k_bin<true>(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 
 // ---- k_rt_binned: fused primary + shadow + shade + resolve over the binned candidates ---------------
 //

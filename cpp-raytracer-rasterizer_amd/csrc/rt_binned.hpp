@@ -33,6 +33,8 @@ constexpr int MAX_BIN_FRAMES = 1 + 6 * MIRT_MAX_LIGHTS;
 
 struct BinFrameDesc {
     float P0[3], Pu[3], Pv[3];   // negD ~ P0 + u*Pu + v*Pv
+    float S[3];                  // the family's ray origin (camera or light position)
+    float ru[3], rv[3], rw[3];   // inverse map: for g = S - P,  (u, v) = (ru.g, rv.g) / (rw.g), valid while rw.g > 0
     float ulo, vlo, du, dv;      // bin (i,j) covers u in [ulo + i*du + pad_lo, ulo + (i+1)*du + pad_hi]
     float pad_lo, pad_hi;
     float dmax;                  // bound on |negD| components over the family
@@ -72,7 +74,11 @@ __device__ __forceinline__ EdgeFn make_edge_fn(float gx, float gy, float gz, con
     return e;
 }
 
-struct TriBinFns { EdgeFn n, p, q, s; float nb; };
+struct TriBinFns {
+    EdgeFn n, p, q, s;
+    float nb;
+    float bu0, bu1, bv0, bv1;    // conservative (u,v) bounding box of the accept region; bu0 > bu1 when unavailable
+};
 
 __device__ __forceinline__ TriBinFns make_bin_fns(const OriginRow &r, const BinFrameDesc &fr)
 {
@@ -86,7 +92,52 @@ __device__ __forceinline__ TriBinFns make_bin_fns(const OriginRow &r, const BinF
     t.s.cv = t.n.cv - t.p.cv - t.q.cv;
     t.s.m = 2.0f * (t.n.m + t.p.m + t.q.m);      // also absorbs the filter's D*2^-20 relative slack
     t.nb = r.r0.w;
+    t.bu0 = 1.0f; t.bu1 = 0.0f; t.bv0 = 1.0f; t.bv1 = 0.0f;      // "no box": every rectangle overlaps
     return t;
+}
+
+// Bounding box of the triangle's accept region in the frame's (u,v) parameters.
+//
+// The edge-function test alone lets through rectangles that lie outside the triangle but are crossed by the
+// extensions of its edges (the classic false positives of half-plane-only rasterisation).  When all three vertices
+// are comfortably in front of the family's projection plane the accept region is the projected triangle, dilated by
+// the same margins the edge functions use: every accepted ray has a >= -m_p, b >= -m_q, s >= -m_s, i.e. lies in the
+// triangle grown about its incentre by (1 + d/r_in), d = max margin distance, r_in = inradius.  The box of the three
+// projected vertices, padded by that growth and by the rounding of the projection itself, therefore contains every
+// accepted ray.  Ill-conditioned cases (a vertex near or behind the plane, slivers whose margin is not small against
+// the inradius) simply keep "no box" and rely on the edge functions, which are always valid.
+__device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const BinFrameDesc &fr)
+{
+    float us[3], vs[3], pad = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float gx = fr.S[0] - t15[3 * j], gy = fr.S[1] - t15[3 * j + 1], gz = fr.S[2] - t15[3 * j + 2];
+        const float w = fr.rw[0] * gx + fr.rw[1] * gy + fr.rw[2] * gz;
+        const float wm = fabsf(fr.rw[0] * gx) + fabsf(fr.rw[1] * gy) + fabsf(fr.rw[2] * gz);
+        if (!(w > 0.00390625f * wm)) return;                       // vertex not clearly in front (also NaN)
+        const float un = fr.ru[0] * gx + fr.ru[1] * gy + fr.ru[2] * gz, vn = fr.rv[0] * gx + fr.rv[1] * gy + fr.rv[2] * gz;
+        const float um = fabsf(fr.ru[0] * gx) + fabsf(fr.ru[1] * gy) + fabsf(fr.ru[2] * gz);
+        const float vm = fabsf(fr.rv[0] * gx) + fabsf(fr.rv[1] * gy) + fabsf(fr.rv[2] * gz);
+        us[j] = un / w; vs[j] = vn / w;
+        // rounding of the projection: numerators carry <= 2^-21 of their term sums, w is within 2^-13 relative
+        pad = fmaxf(pad, 9.5367431640625e-07f * ((um + vm) / w) + 2.44140625e-04f * (fabsf(us[j]) + fabsf(vs[j])));
+    }
+    const float u0 = fminf(fminf(us[0], us[1]), us[2]), u1 = fmaxf(fmaxf(us[0], us[1]), us[2]);
+    const float v0 = fminf(fminf(vs[0], vs[1]), vs[2]), v1 = fmaxf(fmaxf(vs[0], vs[1]), vs[2]);
+    const float ext = fmaxf(u1 - u0, v1 - v0);
+    // inradius = 2*area / perimeter of the projected triangle
+    const float ax = us[1] - us[0], ay = vs[1] - vs[0], bx = us[2] - us[0], by = vs[2] - vs[0], cx = us[2] - us[1], cy = vs[2] - vs[1];
+    const float area2 = fabsf(ax * by - ay * bx);
+    const float per = sqrtf(ax * ax + ay * ay) + sqrtf(bx * bx + by * by) + sqrtf(cx * cx + cy * cy);
+    const float rin = area2 / per;
+    // margin distances of the three edge functions, in (u,v) units
+    const float dp = t.p.m / sqrtf(t.p.cu * t.p.cu + t.p.cv * t.p.cv);
+    const float dq = t.q.m / sqrtf(t.q.cu * t.q.cu + t.q.cv * t.q.cv);
+    const float ds = t.s.m / sqrtf(t.s.cu * t.s.cu + t.s.cv * t.s.cv);
+    const float d = fmaxf(fmaxf(dp, dq), ds) + pad;
+    if (!(d < 0.125f * rin)) return;                               // sliver / degenerate: no box (also NaN, rin == 0)
+    const float grow = 1.25f * (d / rin) * ext + 2.0f * pad + 1.0e-6f * ext;
+    t.bu0 = u0 - grow; t.bu1 = u1 + grow; t.bv0 = v0 - grow; t.bv1 = v1 + grow;
 }
 
 __device__ __forceinline__ void fn_range(const EdgeFn &e, float u0, float u1, float v0, float v1, float *lo, float *hi)
@@ -107,7 +158,8 @@ __device__ __forceinline__ bool rect_may_hit(const TriBinFns &t, float u0, float
     const float T = 2.384185791015625e-07f;      // |e1e2b| below 2^-22 may underflow t to +-0, which passes t >= 0
     const bool pos = (nhi > -t.n.m) && (phi >= -t.p.m) && (qhi >= -t.q.m) && (shi >= -t.s.m) && (t.nb > -T);
     const bool neg = (nlo < t.n.m) && (plo <= t.p.m) && (qlo <= t.q.m) && (slo <= t.s.m) && (t.nb < T);
-    return pos || neg;
+    const bool box = (t.bu0 > t.bu1) || (u1 >= t.bu0 && u0 <= t.bu1 && v1 >= t.bv0 && v0 <= t.bv1);
+    return (pos || neg) && box;
 }
 
 // Which light-cube face and bin a shadow ray with negD = rd belongs to.  Returns the global bin index.

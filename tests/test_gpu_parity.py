@@ -226,6 +226,17 @@ def test_raster_soup(oracle, n, W, H):
     _raster_compare(oracle, tris, (0, 0, -3.5), oracle.rot_from_yaw(0.0, 1.01), float(H), W, H, DEFAULT_LIGHT, cull_flags=0)
 
 
+def test_staging_planes_grow_together(oracle):
+    """Regression: a staging plane first requested by a small frame (depth, here) must be as large as the planes
+    that larger frames already grew; render big RT -> tiny raster -> medium raster."""
+    tris = mirt.scene_soup(3, 50, 0.3)
+    rot = oracle.rot_from_yaw(0.0, 1.0)
+    _rt_compare(oracle, tris, (0, 0, -2), rot, 180.0, 640, 360, DEFAULT_LIGHT)
+    rotr = oracle.rot_from_yaw(0.0, 1.01)
+    _raster_compare(oracle, tris, (0, 0, -3.5), rotr, 32.0, 32, 32, DEFAULT_LIGHT, cull_flags=0)
+    _raster_compare(oracle, tris, (0, 0, -3.5), rotr, 200.0, 320, 200, DEFAULT_LIGHT, cull_flags=0)
+
+
 def test_raster_everything_culled(oracle):
     tris = mirt.scene_cornell()
     view = mirt.make_view((0, 0, -3), oracle.rot_from_yaw(0.0, 1.01), 100.0, 128, 128)
