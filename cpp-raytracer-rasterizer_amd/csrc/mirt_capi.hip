@@ -349,7 +349,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         g.bin_key_valid = false;
     }
     if (!g.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_frames), sizeof(BinFrameDesc) * MAX_BIN_FRAMES));
-    if (!g.d_bin_counters) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_bin_counters), 16));
+    if (!g.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_bin_counters), 16)); HIP_TRY(hipMemset(g.d_bin_counters, 0, 16)); }
     if (!g.d_entries) {
         const size_t cap = (size_t)1 << 20;
         if ((rc = dev_realloc(&g.d_entries, cap))) return rc;
@@ -394,6 +394,21 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
         }
         g.bin_entries = total;
+#ifdef MIRT_BIN_STATS
+        {
+            uint32_t c[4];
+            (void)hipMemcpy(c, g.d_bin_counters, 16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mirt bin stats] tris=%d frames=%d cells/tri=%u  L0 passes=%u  L1 passes=%u  entries=%u  bins=%u\n",
+                    g.n, nframes, gi.cells_per_tri, c[2], c[3], total, nbins);
+            for (int fi = 0; fi < nframes; fi++) {
+                uint32_t a = 0, b = 0;
+                const uint32_t end = (fi + 1 < nframes) ? frames[fi + 1].base : nbins;
+                (void)hipMemcpy(&a, g.d_bin_off + frames[fi].base, 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&b, g.d_bin_off + end, 4, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[mirt bin stats]   frame %d: %u entries\n", fi, b - a);
+            }
+        }
+#endif
         g.bin_key = key;
         g.bin_key_valid = true;
     }

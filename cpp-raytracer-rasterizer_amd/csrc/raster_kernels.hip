@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_scan_sums(uint32_t *__restrict__ sums, 
         if (threadIdx.x == 0) s_carry += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { counters[0] = s_carry; counters[1] = 0; }
+    if (threadIdx.x == 0) { counters[0] = s_carry; counters[1] = 0; }    // [2],[3] are left to the caller (debug statistics)
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(uint32_t *__restrict__ data, int n, const uint32_t *__restrict__ sums,

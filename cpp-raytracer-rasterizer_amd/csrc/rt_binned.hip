@@ -9,29 +9,30 @@ namespace mirt {
 // ---- hierarchical binning: three levels of the same conservative rectangle test, one kernel -----------
 //
 //   level 0  one THREAD per (triangle, frame, 64x64-bin cell): one rectangle test
-//   level 1  the wave then takes its surviving lanes one at a time (ballot loop, edge functions broadcast with
-//            v_readlane): lane = one of the cell's 8x8 coarse cells (8x8 bins each)
+//   level 1  the wave then takes its surviving lanes one at a time (ballot loop, item broadcast with v_readlane):
+//            lane = one of the cell's 8x8 coarse cells (8x8 bins each)
 //   level 2  for every surviving coarse cell: lane = one of its 64 bins -> count (pass 1) or fill (pass 2)
 // All 64 lanes always work on the same item, so triangle size does not cause divergence, and no work queue
 // (hence no contended queue counter) is needed.  COUNT and FILL run the identical tests, so the fill pass
 // finds exactly the slots the count pass reserved.
+//
+// The rectangle test of rt_binned.hpp (rect_may_hit) is evaluated here in "folded" form.  The sign of e1e2b
+// decides which of its two branches can hold (t >= 0 needs sign(e1e2d) == sign(e1e2b)), so the four functions
+// are multiplied by that sign and their margin is added once per item:  F_k = sgn * g_k + m_k  must reach >= 0
+// somewhere in the rectangle for all k.  On the regular bin grid the maximum of an affine function over the cell
+// that starts at bin (I, J) and spans K bins is itself affine in (I, J):
+//     max F = A + I*Bu + J*Bv + max(su*pad_lo, su*(K*du + pad_hi)) + max(sv*pad_lo, sv*(K*dv + pad_hi))
+// i.e. two FMAs per function and cell.  The (u,v) box of add_bbox() becomes a range of bin indices.
 constexpr int BIN_L0 = BIN_COARSE * BIN_COARSE;       // 64 bins per level-0 cell side
 
-__device__ __forceinline__ float bcast(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
-__device__ __forceinline__ EdgeFn bcast(const EdgeFn &e, int lane)
-{
-    EdgeFn r;
-    r.c0 = bcast(e.c0, lane); r.cu = bcast(e.cu, lane); r.cv = bcast(e.cv, lane); r.m = bcast(e.m, lane);
-    return r;
-}
+struct BinItem {
+    float A1[4], A2[4], Bu[4], Bv[4];     // level-1 (K = 8) and level-2 (K = 1) constants, per-bin slopes
+    float lou, hiu, lov, hiv;             // box as bin-index ranges: cell [I, I+K) overlaps iff I+K >= lou && I <= hiu
+};
 
-// rectangle of bins [i0,i1) x [j0,j1) in the frame's (u,v) parameters
-__device__ __forceinline__ bool bins_may_hit(const TriBinFns &t, const BinFrameDesc &fr, int i0, int i1, int j0, int j1)
-{
-    const float u0 = fr.ulo + (float)i0 * fr.du + fr.pad_lo, u1 = fr.ulo + (float)i1 * fr.du + fr.pad_hi;
-    const float v0 = fr.vlo + (float)j0 * fr.dv + fr.pad_lo, v1 = fr.vlo + (float)j1 * fr.dv + fr.pad_hi;
-    return rect_may_hit(t, u0, u1, v0, v1);
-}
+__device__ __forceinline__ float bcastf(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+
+__device__ __forceinline__ float corner(float s, float lo, float hi) { return fmaxf(s * lo, s * hi); }
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
@@ -46,43 +47,94 @@ __global__ __launch_bounds__(256) void k_bin(const float *__restrict__ tris15, c
     if (c < gi.cam_cells) { frame = 0; cx = c % gi.cam_cells_x; cy = gi.cam_cell_y0 + c / gi.cam_cells_x; }
     else { frame = 1 + (c - gi.cam_cells); cx = 0; cy = 0; }
     bool pass0 = false;
-    TriBinFns t;
-    memset(&t, 0, sizeof t);
+    BinItem it;
+    memset(&it, 0, sizeof it);
     if (tri < (uint32_t)n) {
         const BinFrameDesc &fr = bs.frames[frame];
         const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
-        t = make_bin_fns(row, fr);
+        TriBinFns t = make_bin_fns(row, fr);
         add_bbox(t, tris15 + (size_t)15 * tri, fr);
-        const int i0 = cx * BIN_L0, i1 = min((int)(cx + 1) * BIN_L0, fr.nbu);
+        const float T = 2.384185791015625e-07f;       // |e1e2b| < 2^-22: t may underflow to +-0, either sign of e1e2d passes
+        const bool both = fabsf(t.nb) < T || !(t.nb == t.nb);
+        const float sgn = t.nb < 0.0f ? -1.0f : 1.0f;
+        const EdgeFn *fn[4] = { &t.n, &t.p, &t.q, &t.s };
+        float A0[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float su = sgn * fn[k]->cu, sv = sgn * fn[k]->cv;
+            // value at the (unpadded) origin corner of bin (0,0), margin folded in
+            const float base = sgn * fn[k]->c0 + fn[k]->m + su * fr.ulo + sv * fr.vlo;
+            it.Bu[k] = su * fr.du;
+            it.Bv[k] = sv * fr.dv;
+            const float inf = __builtin_huge_valf();
+            A0[k] = both ? inf : base + corner(su, fr.pad_lo, (float)BIN_L0 * fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, (float)BIN_L0 * fr.dv + fr.pad_hi);
+            it.A1[k] = both ? inf : base + corner(su, fr.pad_lo, (float)BIN_COARSE * fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, (float)BIN_COARSE * fr.dv + fr.pad_hi);
+            it.A2[k] = both ? inf : base + corner(su, fr.pad_lo, fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, fr.dv + fr.pad_hi);
+            if (both) { it.Bu[k] = 0.0f; it.Bv[k] = 0.0f; }
+        }
+        const float inf = __builtin_huge_valf();
+        if (t.bstate == BOX_VALID) {
+            // bin-index ranges, widened by 2^-18 (relative) against the rounding of this conversion
+            it.lou = (t.bu0 - fr.ulo - fr.pad_hi) / fr.du; it.hiu = (t.bu1 - fr.ulo - fr.pad_lo) / fr.du;
+            it.lov = (t.bv0 - fr.vlo - fr.pad_hi) / fr.dv; it.hiv = (t.bv1 - fr.vlo - fr.pad_lo) / fr.dv;
+            it.lou -= 3.814697265625e-06f * (1.0f + fabsf(it.lou)); it.hiu += 3.814697265625e-06f * (1.0f + fabsf(it.hiu));
+            it.lov -= 3.814697265625e-06f * (1.0f + fabsf(it.lov)); it.hiv += 3.814697265625e-06f * (1.0f + fabsf(it.hiv));
+        } else if (t.bstate == BOX_EMPTY) {
+            it.lou = it.lov = inf; it.hiu = it.hiv = -inf;
+        } else {
+            it.lou = it.lov = -inf; it.hiu = it.hiv = inf;
+        }
+        // level 0: the cell of 64x64 bins starting at bin (cx*64, cy*64)
+        const float I = (float)(cx * BIN_L0), J = (float)(cy * BIN_L0);
         const int j0 = max((int)cy * BIN_L0, fr.j0), j1 = min((int)(cy + 1) * BIN_L0, fr.j1);
-        pass0 = j1 > j0 && bins_may_hit(t, fr, i0, i1, j0, j1);
+        bool ok = j1 > j0 && (int)(cx * BIN_L0) < fr.nbu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) ok = ok && (__builtin_fmaf(J, it.Bv[k], __builtin_fmaf(I, it.Bu[k], A0[k])) >= 0.0f);
+        ok = ok && (I + (float)BIN_L0 >= it.lou) && (I <= it.hiu) && (J + (float)BIN_L0 >= it.lov) && (J <= it.hiv);
+        pass0 = ok;
     }
     unsigned long long m0 = __ballot(pass0);
+#ifdef MIRT_BIN_STATS
+    if (!FILL && lane == 0) atomicAdd(&bs.counters[2], (uint32_t)__popcll(m0));
+#endif
     while (m0) {
         const int src = __builtin_ctzll(m0);
         m0 &= m0 - 1ull;
         // the surviving lane's item, made wave-uniform
-        TriBinFns u;
-        u.n = bcast(t.n, src); u.p = bcast(t.p, src); u.q = bcast(t.q, src); u.s = bcast(t.s, src); u.nb = bcast(t.nb, src);
-        u.bu0 = bcast(t.bu0, src); u.bu1 = bcast(t.bu1, src); u.bv0 = bcast(t.bv0, src); u.bv1 = bcast(t.bv1, src);
+        BinItem u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { u.A1[k] = bcastf(it.A1[k], src); u.A2[k] = bcastf(it.A2[k], src); u.Bu[k] = bcastf(it.Bu[k], src); u.Bv[k] = bcastf(it.Bv[k], src); }
+        u.lou = bcastf(it.lou, src); u.hiu = bcastf(it.hiu, src); u.lov = bcastf(it.lov, src); u.hiv = bcastf(it.hiv, src);
         const uint32_t utri = (uint32_t)__builtin_amdgcn_readlane((int)tri, src);
         const uint32_t ufr = (uint32_t)__builtin_amdgcn_readlane((int)frame, src);
         const uint32_t ucx = (uint32_t)__builtin_amdgcn_readlane((int)cx, src), ucy = (uint32_t)__builtin_amdgcn_readlane((int)cy, src);
         const BinFrameDesc &fr = bs.frames[ufr];
+        const int nbu = fr.nbu, fj0 = fr.j0, fj1 = fr.j1;
+        const uint32_t fbase = fr.base;
         // level 1: lane = coarse cell (8x8 bins) inside the level-0 cell
-        const uint32_t ccx = ucx * BIN_COARSE + (lane & 7), ccy = ucy * BIN_COARSE + (lane >> 3);
-        const int ci0 = ccx * BIN_COARSE, ci1 = min((int)(ccx + 1) * BIN_COARSE, fr.nbu);
-        const int cj0 = max((int)ccy * BIN_COARSE, fr.j0), cj1 = min((int)(ccy + 1) * BIN_COARSE, fr.j1);
-        const bool pass1 = ci0 < fr.nbu && cj1 > cj0 && bins_may_hit(u, fr, ci0, ci1, cj0, cj1);
+        const int ci = (int)(ucx * BIN_L0) + (lane & 7) * BIN_COARSE, cj = (int)(ucy * BIN_L0) + (lane >> 3) * BIN_COARSE;
+        const float CI = (float)ci, CJ = (float)cj;
+        bool pass1 = ci < nbu && cj + BIN_COARSE > fj0 && cj < fj1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) pass1 = pass1 && (__builtin_fmaf(CJ, u.Bv[k], __builtin_fmaf(CI, u.Bu[k], u.A1[k])) >= 0.0f);
+        pass1 = pass1 && (CI + (float)BIN_COARSE >= u.lou) && (CI <= u.hiu) && (CJ + (float)BIN_COARSE >= u.lov) && (CJ <= u.hiv);
         unsigned long long m1 = __ballot(pass1);
+#ifdef MIRT_BIN_STATS
+        if (!FILL && lane == 0) atomicAdd(&bs.counters[3], (uint32_t)__popcll(m1));
+#endif
         while (m1) {
             const int cl = __builtin_ctzll(m1);
             m1 &= m1 - 1ull;
             // level 2: lane = bin inside coarse cell `cl`
-            const int i = (int)(ucx * BIN_COARSE + (cl & 7)) * BIN_COARSE + (lane & 7);
-            const int j = (int)(ucy * BIN_COARSE + (cl >> 3)) * BIN_COARSE + (lane >> 3);
-            if (i < fr.nbu && j >= fr.j0 && j < fr.j1 && bins_may_hit(u, fr, i, i + 1, j, j + 1)) {
-                const uint32_t bin = fr.base + (uint32_t)j * fr.nbu + i;
+            const int i = (int)(ucx * BIN_L0) + (cl & 7) * BIN_COARSE + (lane & 7);
+            const int j = (int)(ucy * BIN_L0) + (cl >> 3) * BIN_COARSE + (lane >> 3);
+            const float FI = (float)i, FJ = (float)j;
+            bool pass2 = i < nbu && j >= fj0 && j < fj1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) pass2 = pass2 && (__builtin_fmaf(FJ, u.Bv[k], __builtin_fmaf(FI, u.Bu[k], u.A2[k])) >= 0.0f);
+            pass2 = pass2 && (FI + 1.0f >= u.lou) && (FI <= u.hiu) && (FJ + 1.0f >= u.lov) && (FJ <= u.hiv);
+            if (pass2) {
+                const uint32_t bin = fbase + (uint32_t)j * nbu + i;
                 if (!FILL) {
                     atomicAdd(&bs.bin_off[bin], 1u);                 // counts, scanned in place afterwards
                 } else {

@@ -77,8 +77,10 @@ __device__ __forceinline__ EdgeFn make_edge_fn(float gx, float gy, float gz, con
 struct TriBinFns {
     EdgeFn n, p, q, s;
     float nb;
-    float bu0, bu1, bv0, bv1;    // conservative (u,v) bounding box of the accept region; bu0 > bu1 when unavailable
+    float bu0, bu1, bv0, bv1;    // conservative (u,v) bounding box of the accept region (state BOX_VALID)
+    int bstate;                  // BOX_NONE: rely on the edge functions; BOX_VALID; BOX_EMPTY: no ray of the family can hit
 };
+enum { BOX_NONE = 0, BOX_VALID = 1, BOX_EMPTY = 2 };
 
 __device__ __forceinline__ TriBinFns make_bin_fns(const OriginRow &r, const BinFrameDesc &fr)
 {
@@ -92,36 +94,50 @@ __device__ __forceinline__ TriBinFns make_bin_fns(const OriginRow &r, const BinF
     t.s.cv = t.n.cv - t.p.cv - t.q.cv;
     t.s.m = 2.0f * (t.n.m + t.p.m + t.q.m);      // also absorbs the filter's D*2^-20 relative slack
     t.nb = r.r0.w;
-    t.bu0 = 1.0f; t.bu1 = 0.0f; t.bv0 = 1.0f; t.bv1 = 0.0f;      // "no box": every rectangle overlaps
+    t.bu0 = t.bu1 = t.bv0 = t.bv1 = 0.0f;
+    t.bstate = BOX_NONE;
     return t;
 }
 
 // Bounding box of the triangle's accept region in the frame's (u,v) parameters.
 //
 // The edge-function test alone lets through rectangles that lie outside the triangle but are crossed by the
-// extensions of its edges (the classic false positives of half-plane-only rasterisation).  When all three vertices
-// are comfortably in front of the family's projection plane the accept region is the projected triangle, dilated by
-// the same margins the edge functions use: every accepted ray has a >= -m_p, b >= -m_q, s >= -m_s, i.e. lies in the
-// triangle grown about its incentre by (1 + d/r_in), d = max margin distance, r_in = inradius.  The box of the three
-// projected vertices, padded by that growth and by the rounding of the projection itself, therefore contains every
-// accepted ray.  Ill-conditioned cases (a vertex near or behind the plane, slivers whose margin is not small against
-// the inradius) simply keep "no box" and rely on the edge functions, which are always valid.
+// extensions of its edges (the classic false positives of half-plane-only rasterisation), and it cannot see that a
+// triangle lies BEHIND the family's projection plane (every edge line still crosses a big rectangle).  Both are
+// settled from the three vertices, g_j = S - v_j, projected with the frame's inverse map (u,v) = (ru.g, rv.g)/(rw.g):
+//
+//  * every accepted ray has a >= -m_p, b >= -m_q, s >= -m_s (the margins the edge functions already use).  With signed
+//    distances to the three projected edge lines the identity  sum(edge_len * dist) = -2*area  holds everywhere, so:
+//  * all three vertices clearly in front (rw.g > 0): the accept region lies inside the projected triangle with each
+//    edge line pushed out by d = largest margin distance -> box of that pushed-out triangle, padded by the rounding
+//    of the projection (BOX_VALID);
+//  * all three clearly behind (rw.g < 0): the projected lines bound the ANTIPODAL triangle, inside which the three
+//    functions have the rejecting sign; a point within margin of all three accepting sides would need d >= r_in.  If
+//    d < r_in/8 no ray of this family can be accepted at all (BOX_EMPTY);
+//  * anything else (a vertex near the plane, degenerate projections, NaN) keeps BOX_NONE and relies on the edge
+//    functions, which are always valid.
 __device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const BinFrameDesc &fr)
 {
     float us[3], vs[3], pad = 0.0f;
+    int front = 0, behind = 0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const float gx = fr.S[0] - t15[3 * j], gy = fr.S[1] - t15[3 * j + 1], gz = fr.S[2] - t15[3 * j + 2];
         const float w = fr.rw[0] * gx + fr.rw[1] * gy + fr.rw[2] * gz;
         const float wm = fabsf(fr.rw[0] * gx) + fabsf(fr.rw[1] * gy) + fabsf(fr.rw[2] * gz);
-        if (!(w > 0.00390625f * wm)) return;                       // vertex not clearly in front (also NaN)
+        front += (w > 0.00390625f * wm);                           // clearly in front / behind: |w| > 2^-8 of its terms
+        behind += (w < -0.00390625f * wm);
         const float un = fr.ru[0] * gx + fr.ru[1] * gy + fr.ru[2] * gz, vn = fr.rv[0] * gx + fr.rv[1] * gy + fr.rv[2] * gz;
         const float um = fabsf(fr.ru[0] * gx) + fabsf(fr.ru[1] * gy) + fabsf(fr.ru[2] * gz);
         const float vm = fabsf(fr.rv[0] * gx) + fabsf(fr.rv[1] * gy) + fabsf(fr.rv[2] * gz);
         us[j] = un / w; vs[j] = vn / w;
-        // rounding of the projection: numerators carry <= 2^-21 of their term sums, w is within 2^-13 relative
-        pad = fmaxf(pad, 9.5367431640625e-07f * ((um + vm) / w) + 2.44140625e-04f * (fabsf(us[j]) + fabsf(vs[j])));
+        // rounding of the projection: un, vn, w each carry <= 2^-22 of their term sums (3 products, 2 sums), the
+        // quotient 2^-24 more:  |du| <= (2^-22*um + |u|*2^-22*wm)/|w| + 2^-24*|u|; doubled for comfort
+        const float iw = 1.0f / fabsf(w);
+        pad = fmaxf(pad, 4.76837158203125e-07f * ((um + fabsf(us[j]) * wm) * iw + (vm + fabsf(vs[j]) * wm) * iw) +
+                             2.384185791015625e-07f * (fabsf(us[j]) + fabsf(vs[j])));
     }
+    if (front != 3 && behind != 3) return;
     const float u0 = fminf(fminf(us[0], us[1]), us[2]), u1 = fmaxf(fmaxf(us[0], us[1]), us[2]);
     const float v0 = fminf(fminf(vs[0], vs[1]), vs[2]), v1 = fmaxf(fmaxf(vs[0], vs[1]), vs[2]);
     const float ext = fmaxf(u1 - u0, v1 - v0);
@@ -135,9 +151,28 @@ __device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const B
     const float dq = t.q.m / sqrtf(t.q.cu * t.q.cu + t.q.cv * t.q.cv);
     const float ds = t.s.m / sqrtf(t.s.cu * t.s.cu + t.s.cv * t.s.cv);
     const float d = fmaxf(fmaxf(dp, dq), ds) + pad;
-    if (!(d < 0.125f * rin)) return;                               // sliver / degenerate: no box (also NaN, rin == 0)
-    const float grow = 1.25f * (d / rin) * ext + 2.0f * pad + 1.0e-6f * ext;
-    t.bu0 = u0 - grow; t.bu1 = u1 + grow; t.bv0 = v0 - grow; t.bv1 = v1 + grow;
+    if (behind == 3) {
+        if (d < 0.125f * rin) t.bstate = BOX_EMPTY;                // needs d < r_in; NaN or rin == 0 keep BOX_NONE
+        return;
+    }
+    // front: the region {dist_i >= -d} is the triangle with every edge line pushed out by d, i.e. the triangle whose
+    // vertex i sits at  V_i - d*(ua + ub)/|ua x ub|  (ua, ub = unit vectors along the two edges leaving V_i; the
+    // offset is d/sin(angle/2) along the outward bisector).  Its box is tight even for needles, whose tip runs far
+    // out along the needle only.  Degenerate corners give a non-finite offset and keep BOX_NONE.
+    const float l01 = sqrtf(ax * ax + ay * ay), l02 = sqrtf(bx * bx + by * by), l12 = sqrtf(cx * cx + cy * cy);
+    const float e01x = ax / l01, e01y = ay / l01, e02x = bx / l02, e02y = by / l02, e12x = cx / l12, e12y = cy / l12;
+    const float dd = 1.25f * d;
+    const float k0 = dd / fabsf(e01x * e02y - e01y * e02x), k1 = dd / fabsf(e01x * e12y - e01y * e12x), k2 = dd / fabsf(e02x * e12y - e02y * e12x);
+    const float px0 = us[0] - k0 * (e01x + e02x), py0 = vs[0] - k0 * (e01y + e02y);
+    const float px1 = us[1] - k1 * (e12x - e01x), py1 = vs[1] - k1 * (e12y - e01y);
+    const float px2 = us[2] + k2 * (e02x + e12x), py2 = vs[2] + k2 * (e02y + e12y);
+    const float slack = 2.0f * pad + 1.0e-6f * ext;
+    const float bu0 = fminf(fminf(px0, px1), px2) - slack, bu1 = fmaxf(fmaxf(px0, px1), px2) + slack;
+    const float bv0 = fminf(fminf(py0, py1), py2) - slack, bv1 = fmaxf(fmaxf(py0, py1), py2) + slack;
+    if (!(bu0 > -1.0e30f && bu1 < 1.0e30f && bv0 > -1.0e30f && bv1 < 1.0e30f)) return;     // also NaN
+    // the pushed-out triangle contains the original one; keep that explicit against rounding of the offsets
+    t.bu0 = fminf(bu0, u0 - slack); t.bu1 = fmaxf(bu1, u1 + slack); t.bv0 = fminf(bv0, v0 - slack); t.bv1 = fmaxf(bv1, v1 + slack);
+    t.bstate = BOX_VALID;
 }
 
 __device__ __forceinline__ void fn_range(const EdgeFn &e, float u0, float u1, float v0, float v1, float *lo, float *hi)
@@ -158,7 +193,8 @@ __device__ __forceinline__ bool rect_may_hit(const TriBinFns &t, float u0, float
     const float T = 2.384185791015625e-07f;      // |e1e2b| below 2^-22 may underflow t to +-0, which passes t >= 0
     const bool pos = (nhi > -t.n.m) && (phi >= -t.p.m) && (qhi >= -t.q.m) && (shi >= -t.s.m) && (t.nb > -T);
     const bool neg = (nlo < t.n.m) && (plo <= t.p.m) && (qlo <= t.q.m) && (slo <= t.s.m) && (t.nb < T);
-    const bool box = (t.bu0 > t.bu1) || (u1 >= t.bu0 && u0 <= t.bu1 && v1 >= t.bv0 && v0 <= t.bv1);
+    const bool box = (t.bstate == BOX_NONE) ||
+                     (t.bstate == BOX_VALID && u1 >= t.bu0 && u0 <= t.bu1 && v1 >= t.bv0 && v0 <= t.bv1);
     return (pos || neg) && box;
 }
 
