@@ -134,25 +134,42 @@ def main():
 
     from mirt.sharding import BandGather
     dev = torch.device("cuda", local_rank)
-    bands = BandGather(H, W, dev)               # this rank's XRGB band (+ the gathered frame on rank 0)
+    depth = 2 if world > 1 else 1
+    bands = BandGather(H, W, dev, depth=depth)  # this rank's XRGB band(s) (+ the gathered frame on rank 0)
     y0, y1 = bands.y0, bands.y1
     mirt_stream = torch.cuda.ExternalStream(mirt.load().mirt_stream(), device=dev)
-    if kind == "rt":
-        render = mirt.prepared_raytrace_device(view, LIGHT, INDIRECT, mode, y0, y1, y0, bands.band.data_ptr(), W * 4)
-    else:
-        render = mirt.prepared_rasterise_device(view, LIGHT, INDIRECT, y0, y1, y0, bands.band.data_ptr(), W * 4)
+    renders = []
+    for b in bands.bands_buf:
+        if kind == "rt":
+            renders.append(mirt.prepared_raytrace_device(view, LIGHT, INDIRECT, mode, y0, y1, y0, b.data_ptr(), W * 4))
+        else:
+            renders.append(mirt.prepared_rasterise_device(view, LIGHT, INDIRECT, y0, y1, y0, b.data_ptr(), W * 4))
+    render = renders[0]
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    rendered = [torch.cuda.Event() for _ in range(depth)]      # band k holds a finished frame
+    gathered = [torch.cuda.Event() for _ in range(depth)]      # band k has been sent and may be overwritten
+    frame_no = [0]
 
     def step():
-        render()
-        if world > 1:
-            # the band is complete on mirt's stream: order the RCCL gather after it, and the next frame's
-            # render (which overwrites the band) after the gather
-            torch.cuda.current_stream().wait_stream(mirt_stream)
-            bands.gather()
-            mirt_stream.wait_stream(torch.cuda.current_stream())
+        if world == 1:
+            render()
+            return
+        # Double-buffered bands: frame i renders into band i%2 on mirt's stream while the RCCL gather of frame i-1
+        # (the other band) is still in flight on the communication stream.  Dependencies are two events per band.
+        k = frame_no[0] % depth
+        frame_no[0] += 1
+        mirt_stream.wait_event(gathered[k])                    # the gather that last read band k has finished
+        renders[k]()
+        rendered[k].record(mirt_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(rendered[k])
+            bands.gather(k)
+            gathered[k].record(comm_stream)
 
     def fence():
         mirt.sync()
+        if comm_stream is not None:
+            comm_stream.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -18,6 +18,7 @@ namespace mirt {
 __global__ void k_prep_origin(const float *, int, const float *, OriginRow *, OriginRow *, uint32_t *);
 template <int P> __global__ void k_rt_brute(const RtFrame);
 template <int P> __global__ void k_rt_small(const RtFrame, int);
+__global__ void k_rt_wave(const RtFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
@@ -229,7 +230,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     // ---- mode: brute force for small scenes, binned otherwise; unsafe operands always render exact brute ----
     static const int auto_threshold = [] { const char *e = getenv("MIRT_BIN_THRESHOLD"); return e ? atoi(e) : 512; }();
     static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 1; return (p == 2) ? 2 : 1; }();
-    bool binned = (mode == MIRT_RT_BINNED) || (mode == MIRT_RT_AUTO && g.n >= auto_threshold);
+    bool binned = (mode == MIRT_RT_BINNED) ||
+                  (mode == MIRT_RT_AUTO && g.n >= auto_threshold && (long long)view->width * (y1 - y0) > 4096);
     if (!safe) binned = false;
     const int rows = y1 - y0;
 
@@ -258,6 +260,16 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
                        g.d_tris, g.n, g.d_origins, g.d_cam_tab, g.d_light_tab, g.d_flags);
     k_end(MIRT_K_PREP);
 
+    if (!binned && (long long)view->width * rows <= 4096 && g.n >= 1024) {
+        // few rays, many triangles: one wave per ray, lanes over triangles, wavefront min-t reduce
+        const long long nrays = (long long)view->width * rows;
+        k_begin(MIRT_K_TRACE);
+        hipLaunchKernelGGL(k_rt_wave, dim3((unsigned)((nrays + 3) / 4)), dim3(256), 0, g.stream, f);
+        k_end(MIRT_K_TRACE);
+        HIP_TRY(hipGetLastError());
+        call_end();
+        return MIRT_OK;
+    }
     if (!binned) {
         const size_t lds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
         k_begin(MIRT_K_TRACE);

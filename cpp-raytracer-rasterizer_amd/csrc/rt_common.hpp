@@ -144,6 +144,29 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
     return v;
 }
 
+// ---- wavefront min-t primitive ------------------------------------------------------------------------
+// The reference's sequential closest-hit update, `if (closest.distance >= distance)` in index order
+// (raytracer.cpp:243-247), keeps the smallest distance and, among exact ties, the LARGEST index.  Distances are
+// >= 0, so their float bits order as unsigned integers; packing  key = dist_bits << 32 | (0xFFFFFFFF - index)
+// turns that rule into a plain unsigned minimum, which 64 lanes reduce with a 6-step xor butterfly.
+__device__ __forceinline__ unsigned long long min_t_key(float dist, int index)
+{
+    return ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)index);
+}
+__device__ __forceinline__ int min_t_index(unsigned long long key) { return (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)); }
+__device__ __forceinline__ float min_t_dist(unsigned long long key) { return __uint_as_float((uint32_t)(key >> 32)); }
+constexpr unsigned long long MIN_T_NONE = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // FLT_MAX, "index -1"
+
+__device__ __forceinline__ unsigned long long wave_min_key(unsigned long long key)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(key, d);
+        key = o < key ? o : key;
+    }
+    return key;       // every lane holds the wave minimum
+}
+
 // ray-triangle tests a wave executed (second word of the shard); used for the roofline of the binned path
 __device__ __forceinline__ void count_tests(const RtFrame &f, unsigned lane_tests)
 {

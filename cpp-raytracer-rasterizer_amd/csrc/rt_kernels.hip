@@ -373,6 +373,101 @@ __global__ __launch_bounds__(256) void k_rt_small(const RtFrame f, int host_unsa
 template __global__ void k_rt_small<1>(const RtFrame, int);
 template __global__ void k_rt_small<2>(const RtFrame, int);
 
+// ---- k_rt_wave: one WAVE per ray, lanes over triangles, wavefront min-t reduce ----------------------------
+//
+// For frames with few rays and many triangles (a 32x32 pick query into a 100k-triangle scene) one thread per pixel
+// leaves the chip empty.  Here a wave owns one pixel: its 64 lanes stride over the origin table (coalesced 48-byte
+// rows straight from global memory), each keeps its own closest hit, and the wave reduces them with the packed
+// min-t key (rt_common.hpp: wave_min_key).  Shadow rays are the same sweep with an any-hit ballot and early exit.
+// Same filter + exact arithmetic as every other kernel, so results are bit-identical.
+template <bool FILTER>
+__device__ __forceinline__ void wave_body(const RtFrame &f)
+{
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = f.y1 - f.y0;
+    if (ray >= (long long)f.W * rows) return;
+    const int x = (int)(ray % f.W), y = f.y0 + (int)(ray / f.W);
+    const v3 cam = ld3(f.cam);
+    const v3 d = V3((float)x - (float)f.W / 2.0f, (float)y - (float)f.H / 2.0f, f.focal);   // raytracer.cpp:579
+    const v3 nd = neg3(mat3_mul_vec(f.rot, d));                                                // :580, :229
+
+    unsigned long long key = MIN_T_NONE;
+    v3 pos = V3(0.0f, 0.0f, 0.0f);
+    for (int i = lane; i < f.n; i += 64) {
+        const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + i);
+        const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+        const TestDots td = test_dots(r0, r1, r2, nd);
+        if (!FILTER || maybe_hit(td)) {
+            v3 hp;
+            float dist;
+            if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * i, cam, &hp, &dist)) {
+                const unsigned long long k = min_t_key(dist, i);
+                if (k < key) { key = k; pos = hp; }            // lane-local: min distance, then max index
+            }
+        }
+    }
+    const unsigned long long best = wave_min_key(key);
+    const bool hit = best != MIN_T_NONE;
+    const int best_i = hit ? min_t_index(best) : -1;
+    // the lane that holds the winner broadcasts its hit point
+    const int owner = __builtin_ctzll(__ballot(key == best) | (1ull << 63));
+    pos.x = __shfl(pos.x, owner); pos.y = __shfl(pos.y, owner); pos.z = __shfl(pos.z, owner);
+    if (lane == 0 && hit) count_hits(f, 1);
+
+    v3 avg = V3(0.0f, 0.0f, 0.0f);
+    if (hit) {
+        const float *t = f.tris15 + (size_t)15 * best_i;
+        const v3 nDir = normalize3(ld3(t + 9));                       // :300
+        const v3 tcol = ld3(t + 12);
+        v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < f.nlights; k++) {
+            const v3 L = ld3(f.lpos[k]);
+            v3 rd;
+            float r;
+            v3 D = light_term(f, k, pos, nDir, &rd, &r);
+            const float thr = r * 0.99f;                              // :313
+            const OriginRow *tab = f.light_tab + (size_t)k * f.n;
+            bool occluded = false;
+            for (int base = 0; base < f.n && !occluded; base += 64) {
+                const int i = base + lane;
+                bool occ = false;
+                if (i < f.n) {
+                    const float4 *src = reinterpret_cast<const float4 *>(tab + i);
+                    const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+                    const TestDots td = test_dots(r0, r1, r2, rd);    // negD = rDir (:310, :229)
+                    if (!FILTER || maybe_hit(td)) {
+                        v3 hp;
+                        float dist;
+                        occ = exact_hit(td, r0.w, f.tris15 + (size_t)15 * i, L, &hp, &dist) && dist < thr;
+                    }
+                }
+                occluded = __any(occ);                                // any-hit is exact (SURVEY A-5)
+            }
+            if (occluded) D = V3(0.0f, 0.0f, 0.0f);                   // :313-314
+            result = add3(result, D);                                 // :319
+            result2 = add3(result2, result);                          // :322
+        }
+        const v3 Dl = mul3(result2, tcol);                            // :325-326
+        avg = add3(avg, mul3(tcol, add3(Dl, ld3(f.indirect))));       // :584-591
+    }
+    avg = div3s(avg, 1.0f);                                           // :599
+    if (lane != 0) return;
+    const size_t px = (size_t)y * f.W + x;
+    if (f.rgb) st3(f.rgb + 3 * px, avg);
+    if (f.index) f.index[px] = best_i;
+    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)               // :618-620
+        f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+}
+
+__global__ __launch_bounds__(256) void k_rt_wave(const RtFrame f)
+{
+    if (__builtin_amdgcn_readfirstlane(*f.unsafe) == 0u)
+        wave_body<true>(f);
+    else
+        wave_body<false>(f);
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_rt_brute(const RtFrame f)
 {

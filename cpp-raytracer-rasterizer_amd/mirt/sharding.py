@@ -29,7 +29,7 @@ class BandGather:
     slots ARE the frame rows and no extra copy happens.
     """
 
-    def __init__(self, H, W, device, dst=0):
+    def __init__(self, H, W, device, dst=0, depth=1):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.H, self.W, self.dst = H, W, dst
@@ -37,8 +37,10 @@ class BandGather:
         self.y0, self.y1 = self.bands[self.rank]
         self.max_rows = max(b - a for a, b in self.bands)
         self.even = all((b - a) == self.max_rows for a, b in self.bands)
-        # this rank's band buffer (always max_rows tall so every rank sends the same shape)
-        self.band = torch.zeros((self.max_rows, W), dtype=torch.int32, device=device)
+        # this rank's band buffer(s) (always max_rows tall so every rank sends the same shape); with depth 2 the
+        # render of frame i+1 can overlap the gather of frame i (see bench.py)
+        self.bands_buf = [torch.zeros((self.max_rows, W), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.band = self.bands_buf[0]
         self.frame = None
         self.slots = None
         if self.rank == dst:
@@ -50,12 +52,13 @@ class BandGather:
                 self.staging = torch.zeros((self.world, self.max_rows, W), dtype=torch.int32, device=device)
                 self.slots = [self.staging[r] for r in range(self.world)]
 
-    def gather(self):
+    def gather(self, which=0):
         """Collective: after it returns (stream-ordered for nccl), rank dst's `frame` holds the whole image."""
+        band = self.bands_buf[which]
         if self.world == 1:
-            self.frame[self.y0:self.y1].copy_(self.band[: self.y1 - self.y0])
+            self.frame[self.y0:self.y1].copy_(band[: self.y1 - self.y0])
             return self.frame
-        dist.gather(self.band, self.slots if self.rank == self.dst else None, dst=self.dst)
+        dist.gather(band, self.slots if self.rank == self.dst else None, dst=self.dst)
         if self.rank == self.dst and not self.even:
             for r, (a, b) in enumerate(self.bands):
                 self.frame[a:b].copy_(self.staging[r, : b - a])

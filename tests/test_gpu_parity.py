@@ -121,6 +121,15 @@ def test_rt_binned_band(oracle):
     assert np.array_equal(out, full["xrgb"])
 
 
+@pytest.mark.parametrize("mode", [mirt.RT_BRUTE, mirt.RT_AUTO])
+def test_rt_wave_per_ray_min_t(oracle, mode):
+    """Few rays, many triangles: one wave per ray, lanes over triangles, closest hit by the wavefront min-t key
+    (distance bits << 32 | ~index): the `>=` tie rule and every colour must still match bit for bit."""
+    tris = np.concatenate([mirt.scene_soup(41, 3000, 0.2), mirt.scene_cornell()])      # Cornell adds exact ties
+    lights = np.array([[0, -0.5, -0.7, 1, 1, 1, 14], [0.3, 0.2, -0.9, 0.5, 0.7, 1.0, 8]], np.float32)
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.1, 1.0), 24.0, 48, 40, lights, mode=mode)
+
+
 def test_rt_miss_everywhere(oracle):
     """Camera looking away: no hit anywhere -> index -1, black, zero shadow rays."""
     tris = mirt.scene_cornell()
