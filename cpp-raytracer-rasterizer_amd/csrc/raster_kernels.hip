@@ -6,10 +6,11 @@
 // Pipeline per frame (all on one stream, no host round trip once the row count is known):
 //   k_raster_vertex   one thread per triangle: VertexShader x3, row range, rows inside the band
 //   k_scan_*          exclusive scan of rows-per-triangle -> row_base (where each triangle's rows live)
-//   k_raster_edges    one thread per (triangle, edge, field): Interpolate's SEQUENTIAL float accumulation,
-//                     bit for bit (a + k*step would round differently), written into per-row slots
-//   k_raster_spans    one thread per (triangle,row): strict-min / strict-max x over the <=3 edge samples
-//                     -> the span (a.x, b.x] and its zinv / pos3d steps
+//                     (small scenes: both in one single-workgroup launch, k_raster_vertex_scan)
+//   k_raster_edges    one workgroup per triangle: Interpolate's SEQUENTIAL float accumulation, bit for bit
+//                     (a + k*step would round differently), 15 chains staged through LDS into per-row slots; then
+//                     per row strict-min / strict-max x over the <=3 edge samples -> the span (a.x, b.x] and its
+//                     zinv / pos3d steps
 //   k_raster_frag     one wave per span: zinv = a.zinv + zstep*float(i) per fragment and an atomic z-compare:
 //                     atomicMax on the u64 key  zinv_bits<<32 | (0xFFFFFFFF - tri)  (zinv > 0 orders as
 //                     unsigned bits; the reference's strict `>` with in-order triangles = max zinv, lowest
@@ -24,10 +25,8 @@
 namespace mirt {
 
 // ---- VertexShader (rasteriser.cpp:532-546) ------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_raster_vertex(const RasterFrame f)
+__device__ __forceinline__ TriSetup vertex_setup(const RasterFrame &f, int t)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= f.n) return;
     const float *tri = f.tris15 + (size_t)15 * t;
     const v3 cam = ld3(f.cam);
     TriSetup s;
@@ -49,6 +48,14 @@ __global__ __launch_bounds__(256) void k_raster_vertex(const RasterFrame f)
     const int lo = max(s.minY, f.y0), hi = min(s.maxY, f.y1 - 1);
     s.r0 = lo;
     s.rows = (ok && hi >= lo) ? hi - lo + 1 : 0;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_raster_vertex(const RasterFrame f)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= f.n) return;
+    const TriSetup s = vertex_setup(f, t);
     f.scratch.setup[t] = s;
     f.scratch.row_base[t] = (uint32_t)s.rows;     // scanned in place by k_scan_*
 }
@@ -121,93 +128,160 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint32_t *__restrict__ data,
     if (blockIdx.x == 0 && threadIdx.x == 0) data[n] = counters[0];
 }
 
-// ---- Interpolate along the three edges (rasteriser.cpp:615-637, called from :706-715) -----------------
-// One thread per (triangle, edge, field).  `current += step` is a dependent float chain, so each chain is a
-// thread of its own; 15 chains per triangle run side by side.  field: 0 = x, 1 = zinv, 2..4 = pos3d.
-__global__ __launch_bounds__(256) void k_raster_edges(const RasterFrame f)
+// VertexShader + the row-count scan in ONE single-workgroup launch, for scenes of a few thousand triangles (the
+// reference's own scene has 30): four tiny dependent launches cost more in launch gaps than in work.
+__global__ __launch_bounds__(256) void k_raster_vertex_scan(const RasterFrame f)
 {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    const int t = id / 15;
-    if (t >= f.n) return;
-    const TriSetup &s = f.scratch.setup[t];
-    const int rows = s.rows;
-    if (rows == 0) return;
-    const int e = (id % 15) / 5, fld = id % 5;
-    const int i = e, j = (e + 1) % 3;
-    const int ya = s.y[i], yb = s.y[j];
-    const int N = abs(ya - yb) + 1;                                  // :713
-    const float div = (float)max(N - 1, 1);                          // :622
-    float cur, step;
-    if (fld == 0) { cur = (float)s.x[i]; step = (float)(s.x[j] - s.x[i]) / div; }
-    else if (fld == 1) { cur = s.zinv[i]; step = (s.zinv[j] - s.zinv[i]) / div; }
-    else { cur = s.p[i][fld - 2]; step = (s.p[j][fld - 2] - s.p[i][fld - 2]) / div; }
-    const int dir = (yb > ya) - (yb < ya);
-    const int r0 = s.r0, r1 = s.r0 + rows;                           // band rows [r0, r1)
-    const size_t base = f.scratch.row_base[t];
-    if (base + (size_t)rows > f.scratch.cap_rows) { if (fld == 0 && e == 0) atomicExch(&f.scratch.counters[1], 1u); return; }
-    // Samples are y = ya, ya+dir, ... yb.  Only those inside the band are stored, but the float chain has to
-    // be walked from the edge's first sample: `skip` pure additions, then `cnt` store+add steps.
-    int skip, ystart, cnt;
-    if (dir > 0) { ystart = max(ya, r0); skip = ystart - ya; cnt = min(yb, r1 - 1) - ystart + 1; }
-    else if (dir < 0) { ystart = min(ya, r1 - 1); skip = ya - ystart; cnt = ystart - max(yb, r0) + 1; }
-    else { ystart = ya; skip = 0; cnt = (ya >= r0 && ya < r1) ? 1 : 0; }
-    if (cnt <= 0) return;
-#pragma unroll 8
-    for (int k = 0; k < skip; k++) cur += step;                      // :632-635, sequential on purpose
-    float *ptr = f.scratch.slots + ((base + (size_t)(ystart - r0)) * 3 + e) * SLOT_FIELDS + fld;
-    const ptrdiff_t stride = (ptrdiff_t)dir * 3 * SLOT_FIELDS;
-    if (fld == 0) {
-#pragma unroll 4
-        for (int k = 0; k < cnt; k++) { *ptr = __int_as_float(f2i_x86(cur)); ptr += stride; cur += step; }   // result[i].x = current.x (:628)
-    } else {
-#pragma unroll 4
-        for (int k = 0; k < cnt; k++) { *ptr = cur; ptr += stride; cur += step; }
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < f.n; base += SCAN_ITEMS) {
+        const int i0 = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v[i] = 0u;
+            if (i0 + i < f.n) {
+                const TriSetup s = vertex_setup(f, i0 + i);
+                f.scratch.setup[i0 + i] = s;
+                v[i] = (uint32_t)s.rows;
+            }
+        }
+        uint32_t total;
+        uint32_t off = block_exclusive_scan_256x4(v, &total) + s_carry;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { if (i0 + i < f.n) f.scratch.row_base[i0 + i] = off; off += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
     }
-}
-
-__device__ __forceinline__ int find_tri(const uint32_t *row_base, int n, uint32_t r)
-{
-    int lo = 0, hi = n;                      // row_base[lo] <= r < row_base[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (row_base[mid] <= r) lo = mid; else hi = mid;
-    }
-    return lo;
+    if (threadIdx.x == 0) { f.scratch.row_base[f.n] = s_carry; f.scratch.counters[0] = s_carry; f.scratch.counters[1] = 0; }
 }
 
 // ---- left/right per row (rasteriser.cpp:716-733) and the span constants (:646-649) --------------------
-__global__ __launch_bounds__(256) void k_raster_spans(const RasterFrame f)
+__device__ __forceinline__ void build_span(const RasterFrame &f, const TriSetup &s, int t, uint32_t r, int y)
 {
-    const uint32_t R = min(f.scratch.counters[0], (uint32_t)f.scratch.cap_rows);
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-        const int t = find_tri(f.scratch.row_base, f.n, r);
-        const TriSetup &s = f.scratch.setup[t];
-        const int y = s.r0 + (int)(r - f.scratch.row_base[t]);
-        int lx = INT_MAX, rx = -INT_MAX;
-        float lz = 0.0f, rz = 0.0f;
-        v3 lp = V3(0, 0, 0), rp = V3(0, 0, 0);
+    int lx = INT_MAX, rx = -INT_MAX;
+    float lz = 0.0f, rz = 0.0f;
+    v3 lp = V3(0, 0, 0), rp = V3(0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 3; e++) {
-            const int ya = s.y[e], yb = s.y[(e + 1) % 3];
-            if (y < min(ya, yb) || y > max(ya, yb)) continue;       // this edge has no sample on this row
-            const float *slot = f.scratch.slots + ((size_t)r * 3 + e) * SLOT_FIELDS;
-            const int x = __float_as_int(slot[0]);
-            if (x < lx) { lx = x; lz = slot[1]; lp = V3(slot[2], slot[3], slot[4]); }   // strict <, first edge wins ties
-            if (x > rx) { rx = x; rz = slot[1]; rp = V3(slot[2], slot[3], slot[4]); }   // strict >
-        }
-        Span sp;
-        sp.tri = t; sp.y = y;
-        sp.ax = lx;
-        const long long d = (long long)rx - (long long)lx;
-        sp.dx = (d > 0 && d < (1ll << 22)) ? (int)d : 0;
-        const float fdx = (float)sp.dx;
-        sp.azinv = lz;
-        sp.zstep = (rz - lz) / fdx;                                   // :648 (unused when dx == 0)
-        const v3 ps = div3s(sub3(rp, lp), fdx);                       // :649
-        sp.ap[0] = lp.x; sp.ap[1] = lp.y; sp.ap[2] = lp.z;
-        sp.pstep[0] = ps.x; sp.pstep[1] = ps.y; sp.pstep[2] = ps.z;
-        f.scratch.spans[r] = sp;
+    for (int e = 0; e < 3; e++) {
+        const int ya = s.y[e], yb = s.y[(e + 1) % 3];
+        if (y < min(ya, yb) || y > max(ya, yb)) continue;       // this edge has no sample on this row
+        const float *slot = f.scratch.slots + ((size_t)r * 3 + e) * SLOT_FIELDS;
+        const int x = __float_as_int(slot[0]);
+        if (x < lx) { lx = x; lz = slot[1]; lp = V3(slot[2], slot[3], slot[4]); }   // strict <, first edge wins ties
+        if (x > rx) { rx = x; rz = slot[1]; rp = V3(slot[2], slot[3], slot[4]); }   // strict >
     }
+    Span sp;
+    sp.tri = t; sp.y = y;
+    sp.ax = lx;
+    const long long d = (long long)rx - (long long)lx;
+    sp.dx = (d > 0 && d < (1ll << 22)) ? (int)d : 0;
+    const float fdx = (float)sp.dx;
+    sp.azinv = lz;
+    sp.zstep = (rz - lz) / fdx;                                   // :648 (unused when dx == 0)
+    const v3 ps = div3s(sub3(rp, lp), fdx);                       // :649
+    sp.ap[0] = lp.x; sp.ap[1] = lp.y; sp.ap[2] = lp.z;
+    sp.pstep[0] = ps.x; sp.pstep[1] = ps.y; sp.pstep[2] = ps.z;
+    f.scratch.spans[r] = sp;
+}
+
+// ---- Interpolate along the three edges (rasteriser.cpp:615-637, called from :706-715) -----------------
+// `current += step` is a dependent float chain (a + k*step would round differently), so it cannot be split
+// across threads: 15 chains per triangle (3 edges x {x, zinv, pos3d.xyz}) run in 15 lanes of one workgroup.
+// The chain lanes only touch LDS (a global store per step made every step cost ~100 cycles); each EDGE_CHUNK
+// steps the whole workgroup flushes the chunk to the per-row slots in global memory.
+constexpr int EDGE_CHUNK = 512;
+
+struct EdgeWalk { int ystart, dir, skip, cnt; };
+
+__device__ __forceinline__ EdgeWalk edge_walk(const TriSetup &s, int e)
+{
+    // Samples are y = ya, ya+dir, ... yb.  Only those inside the band rows [r0, r1) are stored, but the float
+    // chain has to be walked from the edge's first sample: `skip` pure additions, then `cnt` stored steps.
+    const int ya = s.y[e], yb = s.y[(e + 1) % 3];
+    const int r0 = s.r0, r1 = s.r0 + s.rows;
+    EdgeWalk w;
+    w.dir = (yb > ya) - (yb < ya);
+    if (w.dir > 0) { w.ystart = max(ya, r0); w.skip = w.ystart - ya; w.cnt = min(yb, r1 - 1) - w.ystart + 1; }
+    else if (w.dir < 0) { w.ystart = min(ya, r1 - 1); w.skip = ya - w.ystart; w.cnt = w.ystart - max(yb, r0) + 1; }
+    else { w.ystart = ya; w.skip = 0; w.cnt = (ya >= r0 && ya < r1) ? 1 : 0; }
+    if (w.cnt < 0) w.cnt = 0;
+    return w;
+}
+
+__global__ __launch_bounds__(256) void k_raster_edges(const RasterFrame f)
+{
+    __shared__ float bufs[2][EDGE_CHUNK * 15];
+    const int t = blockIdx.x;
+    const TriSetup &s = f.scratch.setup[t];
+    const int rows = s.rows;
+    if (rows == 0) return;
+    const size_t base = f.scratch.row_base[t];
+    if (base + (size_t)rows > f.scratch.cap_rows) { if (threadIdx.x == 0) atomicExch(&f.scratch.counters[1], 1u); return; }
+
+    const EdgeWalk w0 = edge_walk(s, 0), w1 = edge_walk(s, 1), w2 = edge_walk(s, 2);
+    const int maxcnt = max(max(w0.cnt, w1.cnt), w2.cnt);
+
+    // Roles.  Chain lanes: wave 0 lanes 0..11 carry the twelve float fields (zinv, pos3d.xyz of the three edges),
+    // wave 1 lanes 0..2 the three x chains (which also convert to int) -- a lone wave issues one instruction every
+    // ~5 cycles, so the shorter each chain's loop body, the shorter the walk.  Flush lanes: 120 threads of waves 2-3,
+    // 8 per channel, copy the PREVIOUS chunk from LDS to the per-row slots while the chains fill the next one.
+    const int tid = threadIdx.x;
+    int e = -1, fld = 0;
+    if (tid < 12) { e = tid >> 2; fld = 1 + (tid & 3); }
+    else if (tid >= 64 && tid < 67) { e = tid - 64; fld = 0; }
+    float cur = 0.0f, step = 0.0f;
+    int mycnt = 0;
+    if (e >= 0) {
+        const int i = e, j = (e + 1) % 3;
+        const int N = abs(s.y[i] - s.y[j]) + 1;                      // :713
+        const float div = (float)max(N - 1, 1);                      // :622
+        if (fld == 0) { cur = (float)s.x[i]; step = (float)(s.x[j] - s.x[i]) / div; }
+        else if (fld == 1) { cur = s.zinv[i]; step = (s.zinv[j] - s.zinv[i]) / div; }
+        else { cur = s.p[i][fld - 2]; step = (s.p[j][fld - 2] - s.p[i][fld - 2]) / div; }
+        const EdgeWalk w = (e == 0) ? w0 : (e == 1) ? w1 : w2;
+        mycnt = w.cnt;
+#pragma unroll 8
+        for (int k = 0; k < w.skip; k++) cur += step;                // :632-635, sequential on purpose
+    }
+    const int ft = tid - 128;                                        // flush lane id
+    const bool flusher = ft >= 0 && ft < 120;
+    const int fg = ft / 15, fch = ft - fg * 15, fe = fch / 5;        // 8 lanes per channel
+    const EdgeWalk fw = (fe == 0) ? w0 : (fe == 1) ? w1 : w2;
+    float *slots = f.scratch.slots;
+
+    const int nchunks = (maxcnt + EDGE_CHUNK - 1) / EDGE_CHUNK;
+    for (int ci = 0; ci <= nchunks; ci++) {
+        if (ci < nchunks && e >= 0) {
+            const int c0 = ci * EDGE_CHUNK;
+            const int kend = min(EDGE_CHUNK, mycnt - c0);
+            float *dst = bufs[ci & 1] + e * 5 + fld;
+            if (fld == 0) {
+                // result[i].x = current.x truncates (:628).  |x| stays below 2^21 for in-contract triangles, so the
+                // plain conversion equals the x86 one (f2i_x86) here.
+#pragma unroll 8
+                for (int k = 0; k < kend; k++) { dst[k * 15] = __int_as_float((int)cur); cur += step; }
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < kend; k++) { dst[k * 15] = cur; cur += step; }
+            }
+        }
+        if (ci > 0 && flusher) {
+            const int c0 = (ci - 1) * EDGE_CHUNK;
+            const int kend = min(EDGE_CHUNK, fw.cnt - c0);           // steps of this channel's edge in the chunk
+            const float *src = bufs[(ci - 1) & 1] + fch;
+            // slot of step k: row y = ystart + dir*k  ->  ((base + y - r0)*3 + edge)*5 + field
+            float *dst = slots + ((base + (size_t)(fw.ystart + fw.dir * (c0 + fg) - s.r0)) * 3 + fe) * SLOT_FIELDS + (fch - fe * 5);
+            const ptrdiff_t dstep = (ptrdiff_t)fw.dir * 8 * 3 * SLOT_FIELDS;
+            for (int k = fg; k < kend; k += 8) { *dst = src[k * 15]; dst += dstep; }
+        }
+        __syncthreads();
+    }
+    // all edge samples of this triangle are in its slots (written by this workgroup, barrier above): build the spans
+    __threadfence_block();
+    for (int r = threadIdx.x; r < rows; r += 256) build_span(f, s, t, (uint32_t)(base + r), s.r0 + r);
 }
 
 // ---- fragments with an atomic z-compare (rasteriser.cpp:603-610, 657-669) -----------------------------
@@ -347,8 +421,12 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
 
     begin(MIRT_K_RASTER_SETUP);
     f.scratch = s;
-    hipLaunchKernelGGL(k_raster_vertex, dim3((f.n + 255) / 256), dim3(256), 0, stream, f);
-    enqueue_exclusive_scan(s.row_base, f.n, s.block_sums, s.counters, stream);
+    if (f.n <= 4096) {
+        hipLaunchKernelGGL(k_raster_vertex_scan, dim3(1), dim3(256), 0, stream, f);
+    } else {
+        hipLaunchKernelGGL(k_raster_vertex, dim3((f.n + 255) / 256), dim3(256), 0, stream, f);
+        enqueue_exclusive_scan(s.row_base, f.n, s.block_sums, s.counters, stream);
+    }
 
     // The slot / span tables are sized from the total row count.  It is read back (one 4-byte copy + sync)
     // only when the frame's geometry inputs changed since the last call; otherwise last frame's count holds.
@@ -362,9 +440,8 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
         s.sizing_valid = true;
         f.scratch = s;
     }
-    hipLaunchKernelGGL(k_raster_edges, dim3(((size_t)f.n * 15 + 255) / 256), dim3(256), 0, stream, f);
-    const int span_blocks = (int)min((size_t)4096, (s.cap_rows + 255) / 256);
-    hipLaunchKernelGGL(k_raster_spans, dim3(span_blocks), dim3(256), 0, stream, f);
+    // edge walk + span build, one workgroup per triangle
+    hipLaunchKernelGGL(k_raster_edges, dim3(f.n), dim3(256), 0, stream, f);
     end(MIRT_K_RASTER_SETUP);
 
     begin(MIRT_K_RASTER_FRAG);
