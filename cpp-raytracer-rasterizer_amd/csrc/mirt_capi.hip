@@ -26,6 +26,7 @@ struct RtBinnedFrame {
     uint32_t cam_base;
     uint32_t light_base[MIRT_MAX_LIGHTS];
     int tiles_x;
+    int cube_bins;
 };
 __global__ void k_rt_binned(const RtBinnedFrame);
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
@@ -332,6 +333,11 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         nbins = (uint32_t)c.nbu * c.nbv;
     }
     int nframes = 1;
+    // light-cube resolution: 64 bins per face side measured best from 100k to 1M triangles (tools/sweep_cube.sh:
+    // finer grids shorten the shadow lists a little but pay more in binning); MIRT_CUBE_BINS=128|256 overrides
+    static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
+    int cube_bins = CUBE_BINS_MIN;
+    if (cube_override == 64 || cube_override == 128 || cube_override == 256) cube_bins = cube_override;
     RtBinnedFrame bf;
     memset(&bf, 0, sizeof bf);
     for (int k = 0; k < nlights; k++) {
@@ -345,11 +351,11 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             d.rw[ax] = d.P0[ax]; d.ru[(ax + 1) % 3] = 1.0f; d.rv[(ax + 2) % 3] = 1.0f;   // g = m*(s e_k + u e_k1 + v e_k2)
             memcpy(d.S, lights[k].pos, 12);
             d.dmax = 2.0f;
-            d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / CUBE_BINS; d.dv = 2.0f / CUBE_BINS;
+            d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / (float)cube_bins; d.dv = 2.0f / (float)cube_bins;
             d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
-            d.nbu = CUBE_BINS; d.nbv = CUBE_BINS; d.j0 = 0; d.j1 = CUBE_BINS;
+            d.nbu = cube_bins; d.nbv = cube_bins; d.j0 = 0; d.j1 = cube_bins;
             d.base = nbins; d.tab = 1 + k;
-            nbins += CUBE_BINS * CUBE_BINS;
+            nbins += (uint32_t)(cube_bins * cube_bins);
         }
     }
     if (nbins + 1 > g.cap_bins) {
@@ -374,14 +380,15 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     gi.cam_cells_x = (uint32_t)((frames[0].nbu + L0 - 1) / L0);
     gi.cam_cell_y0 = (uint32_t)(frames[0].j0 / L0);
     gi.cam_cells = gi.cam_cells_x * (uint32_t)((frames[0].j1 + L0 - 1) / L0 - frames[0].j0 / L0);
-    gi.cells_per_tri = gi.cam_cells + (uint32_t)(nframes - 1);
+    gi.face_cells_x = (uint32_t)(cube_bins / L0);
+    gi.cells_per_tri = gi.cam_cells + (uint32_t)(nframes - 1) * gi.face_cells_x * gi.face_cells_x;
     const size_t bin_threads = (size_t)g.n * gi.cells_per_tri;
     const unsigned bin_blocks = (unsigned)((bin_threads + 255) / 256);
 
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
     {
         auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
-        mix(view, sizeof *view); mix(origins, sizeof(float) * 3 * (1 + nlights)); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4);
+        mix(view, sizeof *view); mix(origins, sizeof(float) * 3 * (1 + nlights)); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4); mix(&cube_bins, 4);
     }
 
     BinSet bs;
@@ -431,6 +438,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     bf.bins = bs;
     bf.cam_base = 0;
     bf.tiles_x = frames[0].nbu;
+    bf.cube_bins = cube_bins;
     const int tile_rows = frames[0].j1 - frames[0].j0;
     k_begin(MIRT_K_TRACE);
     hipLaunchKernelGGL(k_rt_binned, dim3((bf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), 0, g.stream, bf);

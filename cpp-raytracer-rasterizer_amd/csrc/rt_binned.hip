@@ -41,11 +41,16 @@ __global__ __launch_bounds__(256) void k_bin(const float *__restrict__ tris15, c
     const int lane = threadIdx.x & 63;
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tri = id / gi.cells_per_tri;
-    // which (frame, level-0 cell) this thread owns: frame 0 has cam_cells cells, every other frame exactly one
+    // which (frame, level-0 cell) this thread owns: frame 0 has cam_cells cells, every cube face face_cells_x^2
     const uint32_t c = id - tri * gi.cells_per_tri;
     uint32_t frame, cx, cy;
     if (c < gi.cam_cells) { frame = 0; cx = c % gi.cam_cells_x; cy = gi.cam_cell_y0 + c / gi.cam_cells_x; }
-    else { frame = 1 + (c - gi.cam_cells); cx = 0; cy = 0; }
+    else {
+        const uint32_t per_face = gi.face_cells_x * gi.face_cells_x, cc = c - gi.cam_cells;
+        frame = 1 + cc / per_face;
+        const uint32_t within = cc - (frame - 1) * per_face;
+        cx = within % gi.face_cells_x; cy = within / gi.face_cells_x;
+    }
     bool pass0 = false;
     BinItem it;
     memset(&it, 0, sizeof it);
@@ -163,6 +168,7 @@ struct RtBinnedFrame {
     uint32_t cam_base;                       // bin base of the camera frame
     uint32_t light_base[MIRT_MAX_LIGHTS];    // bin base of face 0 of each light
     int tiles_x;                             // camera bins per row (nbu)
+    int cube_bins;                           // light-cube bins per face side
 };
 
 // order-independent form of the reference's sequential ">=" update (raytracer.cpp:243-247):
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
             float r;
             v3 D = light_term(f, k, pos, nDir, &rd, &r);
             const float thr = r * 0.99f;                   // (:313)
-            const uint32_t bin = cube_bin_of(rd, bf.light_base[k]);
+            const uint32_t bin = cube_bin_of(rd, bf.light_base[k], bf.cube_bins);
             const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
             const OriginRow *tab = f.light_tab + (size_t)k * f.n;
             uint32_t e = beg;

@@ -28,7 +28,7 @@ namespace mirt {
 
 constexpr int BIN_TILE = 8;            // camera bins are 8x8 pixels = one wave64
 constexpr int BIN_COARSE = 8;          // coarse cell = 8x8 fine bins (hierarchical test)
-constexpr int CUBE_BINS = 64;          // per-face light-cube grid is CUBE_BINS x CUBE_BINS
+constexpr int CUBE_BINS_MIN = 64;      // per-face light-cube grid is B x B; B = 64 by default (128 / 256 selectable)
 constexpr int MAX_BIN_FRAMES = 1 + 6 * MIRT_MAX_LIGHTS;
 
 struct BinFrameDesc {
@@ -59,6 +59,7 @@ struct BinSet {
 struct BinGridInfo {
     uint32_t cells_per_tri;      // level-0 cells per triangle over all frames
     uint32_t cam_cells, cam_cells_x, cam_cell_y0;
+    uint32_t face_cells_x;       // level-0 cells per cube-face side (cube_bins / 64); every face has face_cells_x^2
 };
 
 // affine edge function over (u,v) with its safety margin
@@ -199,7 +200,7 @@ __device__ __forceinline__ bool rect_may_hit(const TriBinFns &t, float u0, float
 }
 
 // Which light-cube face and bin a shadow ray with negD = rd belongs to.  Returns the global bin index.
-__device__ __forceinline__ uint32_t cube_bin_of(v3 rd, uint32_t face_base0 /* base of face 0 of this light */)
+__device__ __forceinline__ uint32_t cube_bin_of(v3 rd, uint32_t face_base0 /* base of face 0 of this light */, int cube_bins)
 {
     const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
     int k;
@@ -210,11 +211,12 @@ __device__ __forceinline__ uint32_t cube_bin_of(v3 rd, uint32_t face_base0 /* ba
     const int face = 2 * k + (sgn < 0.0f ? 1 : 0);
     // u, v in [-1,1]; NaN (degenerate ray, never accepted by any triangle) falls into bin 0
     const float u = a / m, v = b / m;
-    int i = (int)floorf((u + 1.0f) * (0.5f * CUBE_BINS));
-    int j = (int)floorf((v + 1.0f) * (0.5f * CUBE_BINS));
-    i = min(max(i, 0), CUBE_BINS - 1);
-    j = min(max(j, 0), CUBE_BINS - 1);
-    return face_base0 + (uint32_t)face * (CUBE_BINS * CUBE_BINS) + (uint32_t)j * CUBE_BINS + (uint32_t)i;
+    const float half = 0.5f * (float)cube_bins;
+    int i = (int)floorf((u + 1.0f) * half);
+    int j = (int)floorf((v + 1.0f) * half);
+    i = min(max(i, 0), cube_bins - 1);
+    j = min(max(j, 0), cube_bins - 1);
+    return face_base0 + (uint32_t)face * (uint32_t)(cube_bins * cube_bins) + (uint32_t)j * cube_bins + (uint32_t)i;
 }
 
 }  // namespace mirt

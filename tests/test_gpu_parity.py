@@ -290,3 +290,37 @@ def test_host_draw_adapter_matches_oracle(oracle, tmp_path, which):
         ref = oracle.rasterise(tris, culled, (0, 0, -3), rot, float(H), W, H, DEFAULT_LIGHT)["xrgb"]
     assert np.array_equal(got, ref)
     assert os.path.getsize(bmp) == 54 + W * 3 * H
+
+
+@pytest.mark.parametrize("cube", [128, 256])
+def test_rt_binned_finer_light_cube(cube):
+    """The light cube is 64/128/256 bins per face depending on the triangle count; force the finer grids on a small
+    scene (MIRT_CUBE_BINS, read once per process) and require binned == brute bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import mirt
+mirt.init(0)
+tris = mirt.scene_soup(13, 4000, 0.1)
+rot = np.zeros(9, np.float32); rot[0] = rot[4] = rot[8] = 1
+view = mirt.make_view((0.1, 0.0, -0.4), rot, 120.0, 320, 200)        # camera inside the soup
+lights = np.array([[0, -0.5, -0.7, 1, 1, 1, 14], [0.3, 0.3, 0.3, 1, 1, 1, 6]], np.float32)
+mirt.scene_upload(tris)
+a = mirt.raytrace(view, lights, mode=mirt.RT_BRUTE)
+b = mirt.raytrace(view, lights, mode=mirt.RT_BINNED)
+assert b["stats"]["mode_used"] == mirt.RT_BINNED
+assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+assert np.array_equal(a["xrgb"], b["xrgb"])
+print("ok")
+''' % os.path.join(root, "cpp-raytracer-rasterizer_amd")
+    mirt.shutdown()
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MIRT_CUBE_BINS=str(cube)),
+                           capture_output=True, text=True, timeout=300)
+    finally:
+        mirt.init(0)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
