@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <cmath>
 
 namespace mirt {
@@ -19,6 +20,13 @@ __global__ void k_prep_origin(const float *, int, const float *, OriginRow *, Or
 template <int P> __global__ void k_rt_brute(const RtFrame);
 template <int P> __global__ void k_rt_small(const RtFrame, int);
 __global__ void k_rt_wave(const RtFrame);
+struct RtTileFrame {
+    RtFrame f;
+    BinFrameDesc cam;
+    int tiles_x, tiles_y;
+    int tiles_per_wave;
+};
+template <int TW> __global__ void k_rt_tile(const RtTileFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
@@ -166,6 +174,56 @@ void call_end() { (void)hipEventRecord(g.ev[EV_CALL1], g.stream); g.stats_pendin
 
 // ---- ray tracer --------------------------------------------------------------------------------------
 
+// The camera ray family negD = -(R0*(x - W/2) + R1*(y - H/2) + R2*f) as a bin frame: (u, v) = pixel (x, y), bins =
+// 8x8-pixel tiles; also carries the inverse map for the bounding boxes (rt_binned.hpp).
+BinFrameDesc make_camera_frame(const mirt_view *view, int y0, int y1)
+{
+    const int W = view->width, H = view->height;
+    BinFrameDesc c;
+    memset(&c, 0, sizeof c);
+    {
+        const float *R = view->rot;                       // column-major: column j = R[3j..3j+2]
+        const float hw = (float)W / 2.0f, hh = (float)H / 2.0f;
+        for (int i = 0; i < 3; i++) {
+            c.Pu[i] = -R[0 + i];
+            c.Pv[i] = -R[3 + i];
+            c.P0[i] = -(R[6 + i] * view->focal - R[0 + i] * hw - R[3 + i] * hh);
+        }
+        float dm = 0.0f;
+        for (int i = 0; i < 3; i++)
+            dm = fmaxf(dm, fabsf(R[0 + i]) * (hw + 1.0f) + fabsf(R[3 + i]) * (hh + 1.0f) + fabsf(R[6 + i]) * fabsf(view->focal));
+        c.dmax = dm;
+        // inverse map for the bounding boxes: h = R^-1 (P - S) = lambda * (x - W/2, y - H/2, f), so with g = S - P
+        //   w = -(R^-1 row 2 . g) / f,  u = (-(R^-1 row 0 . g) + (W/2) f w / f ... ) -> rows below; computed in double
+        {
+            double M[9], inv[9];
+            for (int i = 0; i < 9; i++) M[i] = R[i];
+#define MM(cc, rr) M[(cc) * 3 + (rr)]
+            const double det = MM(0, 0) * (MM(1, 1) * MM(2, 2) - MM(2, 1) * MM(1, 2)) - MM(1, 0) * (MM(0, 1) * MM(2, 2) - MM(2, 1) * MM(0, 2)) +
+                               MM(2, 0) * (MM(0, 1) * MM(1, 2) - MM(1, 1) * MM(0, 2));
+            // inv is row-major here: inv[r*3+c] = (R^-1)(r, c)
+            inv[0] = (MM(1, 1) * MM(2, 2) - MM(2, 1) * MM(1, 2)) / det; inv[1] = -(MM(1, 0) * MM(2, 2) - MM(2, 0) * MM(1, 2)) / det; inv[2] = (MM(1, 0) * MM(2, 1) - MM(2, 0) * MM(1, 1)) / det;
+            inv[3] = -(MM(0, 1) * MM(2, 2) - MM(2, 1) * MM(0, 2)) / det; inv[4] = (MM(0, 0) * MM(2, 2) - MM(2, 0) * MM(0, 2)) / det; inv[5] = -(MM(0, 0) * MM(2, 1) - MM(2, 0) * MM(0, 1)) / det;
+            inv[6] = (MM(0, 1) * MM(1, 2) - MM(1, 1) * MM(0, 2)) / det; inv[7] = -(MM(0, 0) * MM(1, 2) - MM(1, 0) * MM(0, 2)) / det; inv[8] = (MM(0, 0) * MM(1, 1) - MM(1, 0) * MM(0, 1)) / det;
+#undef MM
+            const bool ok = std::isfinite(det) && det != 0.0 && view->focal != 0.0f;
+            for (int i = 0; i < 3; i++) {
+                const double rwd = ok ? -inv[6 + i] / (double)view->focal : 0.0;       // w = h.z / f, h = -R^-1 g
+                c.rw[i] = (float)rwd;
+                c.ru[i] = (float)(ok ? -inv[0 + i] + (double)hw * rwd : 0.0);          // u*w = h.x + (W/2) w
+                c.rv[i] = (float)(ok ? -inv[3 + i] + (double)hh * rwd : 0.0);
+            }
+        }
+        memcpy(c.S, view->pos, 12);
+        c.ulo = 0.0f; c.vlo = 0.0f; c.du = (float)BIN_TILE; c.dv = (float)BIN_TILE;
+        c.pad_lo = 0.0f; c.pad_hi = -1.0f;                // bin i covers pixels 8i .. 8i+7 exactly
+        c.nbu = (W + BIN_TILE - 1) / BIN_TILE; c.nbv = (H + BIN_TILE - 1) / BIN_TILE;
+        c.j0 = y0 / BIN_TILE; c.j1 = (y1 + BIN_TILE - 1) / BIN_TILE;
+        c.base = 0; c.tab = 0;
+    }
+    return c;
+}
+
 int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect, int mode,
                int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index)
 {
@@ -238,6 +296,32 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
 
     // Small scenes (the reference's own 30-triangle Cornell box): one launch, every table built in LDS by the
     // workgroup itself -- no origin-table kernel, no global loads inside the loops.
+    // Scenes of at most 64 triangles (the reference's Cornell box has 30): per-tile candidate masks, one lane per
+    // triangle (rt_tile.hip).  Needs operands inside the filter's proven range, like binning does.
+    static const int tile_w = [] { const char *e = getenv("MIRT_TILE_W"); int w = e ? atoi(e) : 16; return (w == 8 || w == 16 || w == 64) ? w : 0; }();
+    const size_t tile_lds = (size_t)g.n * 16 * (12 + 3 * nlights);
+    if (!binned && safe && tile_w && g.n <= 64 && tile_lds <= 64 * 1024) {
+        RtTileFrame tf;
+        memset(&tf, 0, sizeof tf);
+        tf.f = f;
+        tf.cam = make_camera_frame(view, y0, y1);
+        const int th = 64 / tile_w;
+        tf.tiles_x = (view->width + tile_w - 1) / tile_w;
+        tf.tiles_y = (rows + th - 1) / th;
+        const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
+        tf.tiles_per_wave = (int)std::min<long long>(16, std::max<long long>(1, ntiles / (4 * 2048)));
+        const unsigned blocks = (unsigned)((ntiles + 4LL * tf.tiles_per_wave - 1) / (4LL * tf.tiles_per_wave));
+        HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
+        k_begin(MIRT_K_TRACE);
+        if (tile_w == 8) hipLaunchKernelGGL(k_rt_tile<8>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        else if (tile_w == 16) hipLaunchKernelGGL(k_rt_tile<16>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        else hipLaunchKernelGGL(k_rt_tile<64>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        k_end(MIRT_K_TRACE);
+        HIP_TRY(hipGetLastError());
+        call_end();
+        return MIRT_OK;
+    }
+
     const size_t small_lds = 16 + (size_t)g.n * sizeof(OriginRow) * (2 + nlights);
     if (!binned && small_lds <= 48 * 1024) {
         HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
@@ -288,50 +372,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     g.stats.mode_used = MIRT_RT_BINNED;
     BinFrameDesc frames[MAX_BIN_FRAMES];
     memset(frames, 0, sizeof frames);
-    const int W = view->width, H = view->height;
     uint32_t nbins = 0;
-    {
-        BinFrameDesc &c = frames[0];
-        const float *R = view->rot;                       // column-major: column j = R[3j..3j+2]
-        const float hw = (float)W / 2.0f, hh = (float)H / 2.0f;
-        for (int i = 0; i < 3; i++) {
-            c.Pu[i] = -R[0 + i];
-            c.Pv[i] = -R[3 + i];
-            c.P0[i] = -(R[6 + i] * view->focal - R[0 + i] * hw - R[3 + i] * hh);
-        }
-        float dm = 0.0f;
-        for (int i = 0; i < 3; i++)
-            dm = fmaxf(dm, fabsf(R[0 + i]) * (hw + 1.0f) + fabsf(R[3 + i]) * (hh + 1.0f) + fabsf(R[6 + i]) * fabsf(view->focal));
-        c.dmax = dm;
-        // inverse map for the bounding boxes: h = R^-1 (P - S) = lambda * (x - W/2, y - H/2, f), so with g = S - P
-        //   w = -(R^-1 row 2 . g) / f,  u = (-(R^-1 row 0 . g) + (W/2) f w / f ... ) -> rows below; computed in double
-        {
-            double M[9], inv[9];
-            for (int i = 0; i < 9; i++) M[i] = R[i];
-#define MM(cc, rr) M[(cc) * 3 + (rr)]
-            const double det = MM(0, 0) * (MM(1, 1) * MM(2, 2) - MM(2, 1) * MM(1, 2)) - MM(1, 0) * (MM(0, 1) * MM(2, 2) - MM(2, 1) * MM(0, 2)) +
-                               MM(2, 0) * (MM(0, 1) * MM(1, 2) - MM(1, 1) * MM(0, 2));
-            // inv is row-major here: inv[r*3+c] = (R^-1)(r, c)
-            inv[0] = (MM(1, 1) * MM(2, 2) - MM(2, 1) * MM(1, 2)) / det; inv[1] = -(MM(1, 0) * MM(2, 2) - MM(2, 0) * MM(1, 2)) / det; inv[2] = (MM(1, 0) * MM(2, 1) - MM(2, 0) * MM(1, 1)) / det;
-            inv[3] = -(MM(0, 1) * MM(2, 2) - MM(2, 1) * MM(0, 2)) / det; inv[4] = (MM(0, 0) * MM(2, 2) - MM(2, 0) * MM(0, 2)) / det; inv[5] = -(MM(0, 0) * MM(2, 1) - MM(2, 0) * MM(0, 1)) / det;
-            inv[6] = (MM(0, 1) * MM(1, 2) - MM(1, 1) * MM(0, 2)) / det; inv[7] = -(MM(0, 0) * MM(1, 2) - MM(1, 0) * MM(0, 2)) / det; inv[8] = (MM(0, 0) * MM(1, 1) - MM(1, 0) * MM(0, 1)) / det;
-#undef MM
-            const bool ok = std::isfinite(det) && det != 0.0 && view->focal != 0.0f;
-            for (int i = 0; i < 3; i++) {
-                const double rwd = ok ? -inv[6 + i] / (double)view->focal : 0.0;       // w = h.z / f, h = -R^-1 g
-                c.rw[i] = (float)rwd;
-                c.ru[i] = (float)(ok ? -inv[0 + i] + (double)hw * rwd : 0.0);          // u*w = h.x + (W/2) w
-                c.rv[i] = (float)(ok ? -inv[3 + i] + (double)hh * rwd : 0.0);
-            }
-        }
-        memcpy(c.S, view->pos, 12);
-        c.ulo = 0.0f; c.vlo = 0.0f; c.du = (float)BIN_TILE; c.dv = (float)BIN_TILE;
-        c.pad_lo = 0.0f; c.pad_hi = -1.0f;                // bin i covers pixels 8i .. 8i+7 exactly
-        c.nbu = (W + BIN_TILE - 1) / BIN_TILE; c.nbv = (H + BIN_TILE - 1) / BIN_TILE;
-        c.j0 = y0 / BIN_TILE; c.j1 = (y1 + BIN_TILE - 1) / BIN_TILE;
-        c.base = 0; c.tab = 0;
-        nbins = (uint32_t)c.nbu * c.nbv;
-    }
+    frames[0] = make_camera_frame(view, y0, y1);
+    nbins = (uint32_t)frames[0].nbu * frames[0].nbv;
     int nframes = 1;
     // light-cube resolution: 64 bins per face side measured best from 100k to 1M triangles (tools/sweep_cube.sh:
     // finer grids shorten the shadow lists a little but pay more in binning); MIRT_CUBE_BINS=128|256 overrides

@@ -1,0 +1,236 @@
+// rt_tile.hip -- the ray tracer for scenes of at most 64 triangles (the reference's own Cornell box has 30):
+// everything lives in LDS and every wave prunes the triangle list for its tile before it walks it.
+//
+// k_rt_small (rt_kernels.hip) already keeps the whole scene in LDS, but each of its rays still runs the filter
+// against all n triangles, twice (primary + shadow).  Here a wave owns a TW x (64/TW) pixel tile and first builds
+// two 64-bit candidate masks with ONE lane per triangle:
+//   * primary rays: the conservative rectangle test of rt_binned.hpp (affine edge functions of the camera frame
+//     over the tile's pixel rectangle);
+//   * shadow rays of light k: the same sign conditions evaluated with interval arithmetic over the bounding box of
+//     the wave's shadow-ray directions (three xor-butterfly min/max reductions).
+// The wave then walks only the set bits, in ascending index order, with the very same filter + exact arithmetic as
+// every other kernel -- so the `>=` tie rule and all results stay bit-identical (a pruned triangle could never have
+// been accepted by any ray of the wave).  Per-triangle normalised normals and colours sit in LDS too, and each
+// workgroup renders several tiles per wave so the table build is amortised.
+#include "rt_binned.hpp"
+
+#include <float.h>
+
+namespace mirt {
+
+struct RtTileFrame {
+    RtFrame f;
+    BinFrameDesc cam;        // camera ray family (P0, Pu, Pv, dmax); bins are not used, only the edge functions
+    int tiles_x, tiles_y;    // tiles in the band
+    int tiles_per_wave;
+};
+
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+// interval of g . x for x in the box [lo, hi]
+__device__ __forceinline__ void dot_range(float gx, float gy, float gz, v3 lo, v3 hi, float *rlo, float *rhi)
+{
+    const float ax = gx * lo.x, bx = gx * hi.x, ay = gy * lo.y, by = gy * hi.y, az = gz * lo.z, bz = gz * hi.z;
+    *rlo = fminf(ax, bx) + fminf(ay, by) + fminf(az, bz);
+    *rhi = fmaxf(ax, bx) + fmaxf(ay, by) + fmaxf(az, bz);
+}
+
+// May some ray with negD inside the box [lo, hi] be accepted by the reference's test against this origin row?
+// Same conditions and margins as rect_may_hit (rt_binned.hpp), with |negD| components bounded by 1 (+ rounding).
+__device__ __forceinline__ bool box_may_hit(const float4 &r0, const float4 &r1, const float4 &r2, v3 lo, v3 hi)
+{
+    const float K = 7.62939453125e-06f * 1.0009765625f, C = 9.5367431640625e-07f;      // 2^-17 * dmax, 2^-20
+    const float mn = K * (fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z)) + C;
+    const float mp = K * (fabsf(r1.x) + fabsf(r1.y) + fabsf(r1.z)) + C;
+    const float mq = K * (fabsf(r2.x) + fabsf(r2.y) + fabsf(r2.z)) + C;
+    const float ms = 2.0f * (mn + mp + mq);
+    float nlo, nhi, plo, phi, qlo, qhi, slo, shi;
+    dot_range(r0.x, r0.y, r0.z, lo, hi, &nlo, &nhi);
+    dot_range(r1.x, r1.y, r1.z, lo, hi, &plo, &phi);
+    dot_range(r2.x, r2.y, r2.z, lo, hi, &qlo, &qhi);
+    dot_range(r0.x - r1.x - r2.x, r0.y - r1.y - r2.y, r0.z - r1.z - r2.z, lo, hi, &slo, &shi);
+    const float T = 2.384185791015625e-07f, nb = r0.w;
+    const bool pos = (nhi > -mn) && (phi >= -mp) && (qhi >= -mq) && (shi >= -ms) && (nb > -T);
+    const bool neg = (nlo < mn) && (plo <= mp) && (qlo <= mq) && (slo <= ms) && (nb < T);
+    return pos || neg;
+}
+
+__device__ __forceinline__ bool exact_hit_geo(const TestDots &d, float e1e2b, const float4 *geo, v3 start, v3 *pos, float *dist)
+{
+    const float t = e1e2b / d.den, u = d.pu / d.den, v = d.qv / d.den;      // raytracer.cpp:237
+    if (u + v <= 1.0f && u >= 0.0f && v >= 0.0f && t >= 0.0f) {             // :239
+        const float4 g0 = geo[0], g1 = geo[1], g2 = geo[2];
+        const v3 v0 = V3(g0.x, g0.y, g0.z), e1 = V3(g0.w, g1.x, g1.y), e2 = V3(g1.z, g1.w, g2.x);
+        const v3 p = add3(add3(v0, scale3(e1, u)), scale3(e2, v));          // :241
+        *pos = p;
+        *dist = distance3(start, p);                                         // :242
+        return true;
+    }
+    return false;
+}
+
+template <int TW>
+__device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty, const float4 *s_cam, const float4 *s_geo,
+                                          const float4 *s_fns, const float4 *s_shade, const float4 *s_light)
+{
+    constexpr int TH = 64 / TW;
+    const RtFrame &f = tf.f;
+    const int lane = threadIdx.x & 63, n = f.n;
+    const int x0 = tx * TW, y0 = f.y0 + ty * TH;
+    const int x = x0 + (lane % TW), y = y0 + (lane / TW);
+    const bool ok = x < f.W && y < f.y1;
+    const v3 cam = ld3(f.cam);
+
+    // ---- primary candidates: one lane per triangle tests the tile's pixel rectangle ----
+    bool cand = false;
+    if (lane < n) {
+        TriBinFns t;
+        const float4 a = s_fns[4 * lane], b = s_fns[4 * lane + 1], c = s_fns[4 * lane + 2], d4 = s_fns[4 * lane + 3];
+        t.n.c0 = a.x; t.n.cu = a.y; t.n.cv = a.z; t.n.m = a.w;
+        t.p.c0 = b.x; t.p.cu = b.y; t.p.cv = b.z; t.p.m = b.w;
+        t.q.c0 = c.x; t.q.cu = c.y; t.q.cv = c.z; t.q.m = c.w;
+        t.s.c0 = d4.x; t.s.cu = d4.y; t.s.cv = d4.z; t.s.m = d4.w;
+        t.nb = s_cam[3 * lane].w;
+        t.bstate = BOX_NONE; t.bu0 = t.bu1 = t.bv0 = t.bv1 = 0.0f;
+        cand = rect_may_hit(t, (float)x0, (float)min(x0 + TW - 1, f.W - 1), (float)y0, (float)min(y0 + TH - 1, f.y1 - 1));
+    }
+    unsigned long long pm = __ballot(cand);
+
+    // d = (x - W/2, y - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
+    const v3 d = V3((float)x - (float)f.W / 2.0f, (float)y - (float)f.H / 2.0f, f.focal);
+    const v3 nd = neg3(mat3_mul_vec(f.rot, d));
+    float best_d = FLT_MAX;                                                  // Update() reset (:335-339)
+    int best_i = -1;
+    v3 pos = V3(0.0f, 0.0f, 0.0f);
+    while (pm) {                                                             // ascending index: the `>=` rule holds
+        const int j = __builtin_ctzll(pm);
+        pm &= pm - 1ull;
+        const float4 r0 = s_cam[3 * j], r1 = s_cam[3 * j + 1], r2 = s_cam[3 * j + 2];
+        const TestDots td = test_dots(r0, r1, r2, nd);
+        if (maybe_hit(td)) {
+            v3 hp;
+            float dist;
+            if (exact_hit_geo(td, r0.w, s_geo + 3 * j, cam, &hp, &dist))
+                if (best_d >= dist) { best_d = dist; best_i = j; pos = hp; }     // :243-247
+        }
+    }
+
+    const bool hit = ok && best_i >= 0;
+    count_hits(f, (unsigned long long)__popcll(__ballot(hit)));
+
+    v3 avg = V3(0.0f, 0.0f, 0.0f);
+    if (__any(hit)) {
+        const int bi = best_i >= 0 ? best_i : 0;
+        const float4 sh0 = s_shade[2 * bi], sh1 = s_shade[2 * bi + 1];
+        const v3 nDir = V3(sh0.x, sh0.y, sh0.z);                             // glm::normalize(normal) (:300), per triangle
+        const v3 tcol = V3(sh1.x, sh1.y, sh1.z);
+        v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < f.nlights; k++) {
+            const v3 L = ld3(f.lpos[k]);
+            v3 rd;
+            float r;
+            v3 D = light_term(f, k, pos, nDir, &rd, &r);
+            const float thr = r * 0.99f;                                     // :313
+            const float4 *tab = s_light + (size_t)3 * n * k;
+            // ---- shadow candidates: direction box of the wave's live rays, one lane per triangle ----
+            const float inf = __builtin_huge_valf();
+            const v3 lo = V3(wave_min_f(hit ? rd.x : inf), wave_min_f(hit ? rd.y : inf), wave_min_f(hit ? rd.z : inf));
+            const v3 hi = V3(wave_max_f(hit ? rd.x : -inf), wave_max_f(hit ? rd.y : -inf), wave_max_f(hit ? rd.z : -inf));
+            bool sc = false;
+            if (lane < n) sc = box_may_hit(tab[3 * lane], tab[3 * lane + 1], tab[3 * lane + 2], lo, hi);
+            unsigned long long sm = __ballot(sc);
+            bool live = hit;
+            while (sm) {
+                const int j = __builtin_ctzll(sm);
+                sm &= sm - 1ull;
+                const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
+                const TestDots td = test_dots(r0, r1, r2, rd);               // negD = rDir (:310, :229)
+                if (live && maybe_hit(td)) {
+                    v3 hp;
+                    float dist;
+                    if (exact_hit_geo(td, r0.w, s_geo + 3 * j, L, &hp, &dist) && dist < thr) {
+                        live = false;                                         // occluded (:313-314); any-hit is exact
+                        D = V3(0.0f, 0.0f, 0.0f);
+                    }
+                }
+            }
+            result = add3(result, D);                                        // :319
+            result2 = add3(result2, result);                                 // :322
+        }
+        if (hit) {
+            const v3 Dl = mul3(result2, tcol);                               // :325-326
+            avg = add3(avg, mul3(tcol, add3(Dl, ld3(f.indirect))));          // :584-591
+        }
+    }
+    if (!ok) return;
+    avg = div3s(avg, 1.0f);                                                  // :599
+    const size_t px = (size_t)y * f.W + x;
+    if (f.rgb) st3(f.rgb + 3 * px, avg);
+    if (f.index) f.index[px] = best_i;
+    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)                      // :618-620
+        f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+}
+
+template <int TW>
+__global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_all[];
+    const RtFrame &f = tf.f;
+    const int n = f.n;
+    float4 *s_cam = s_all;                       // 3 rows per triangle
+    float4 *s_geo = s_cam + 3 * n;               // 3
+    float4 *s_fns = s_geo + 3 * n;               // 4: the camera-frame edge functions n, p, q, s
+    float4 *s_shade = s_fns + 4 * n;             // 2: {normalize(normal), -}, {color, -}
+    float4 *s_light = s_shade + 2 * n;           // nlights x 3 rows per triangle
+
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const float *t15 = f.tris15 + (size_t)15 * t;
+        const OriginRow r = make_origin_row(t15, ld3(f.cam));
+        s_cam[3 * t] = r.r0; s_cam[3 * t + 1] = r.r1; s_cam[3 * t + 2] = r.r2;
+        const v3 v0 = ld3(t15), e1 = sub3(ld3(t15 + 3), v0), e2 = sub3(ld3(t15 + 6), v0);       // :216-217
+        s_geo[3 * t] = make_float4(v0.x, v0.y, v0.z, e1.x);
+        s_geo[3 * t + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        s_geo[3 * t + 2] = make_float4(e2.z, 0.0f, 0.0f, 0.0f);
+        const TriBinFns b = make_bin_fns(r, tf.cam);
+        s_fns[4 * t] = make_float4(b.n.c0, b.n.cu, b.n.cv, b.n.m);
+        s_fns[4 * t + 1] = make_float4(b.p.c0, b.p.cu, b.p.cv, b.p.m);
+        s_fns[4 * t + 2] = make_float4(b.q.c0, b.q.cu, b.q.cv, b.q.m);
+        s_fns[4 * t + 3] = make_float4(b.s.c0, b.s.cu, b.s.cv, b.s.m);
+        const v3 nd = normalize3(ld3(t15 + 9));                              // :300
+        s_shade[2 * t] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+        s_shade[2 * t + 1] = make_float4(t15[12], t15[13], t15[14], 0.0f);
+        for (int k = 0; k < f.nlights; k++) {
+            const OriginRow rl = make_origin_row(t15, ld3(f.lpos[k]));
+            float4 *dst = s_light + 3 * ((size_t)k * n + t);
+            dst[0] = rl.r0; dst[1] = rl.r1; dst[2] = rl.r2;
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
+    const long long first = ((long long)blockIdx.x * 4 + wave) * tf.tiles_per_wave;
+    for (int i = 0; i < tf.tiles_per_wave; i++) {
+        const long long tile = first + i;
+        if (tile >= ntiles) break;
+        tile_body<TW>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), s_cam, s_geo, s_fns, s_shade, s_light);
+    }
+}
+
+template __global__ void k_rt_tile<8>(const RtTileFrame);
+template __global__ void k_rt_tile<16>(const RtTileFrame);
+template __global__ void k_rt_tile<64>(const RtTileFrame);
+
+}  // namespace mirt
