@@ -251,7 +251,8 @@ def main():
                            "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
             })
             kt = kernel_ms.get("trace", 0.0)
-            kname = {mirt.RT_BRUTE: "k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute", mirt.RT_BINNED: "k_rt_binned"}[st["mode_used"]]
+            kname = {mirt.RT_BRUTE: "k_rt_tile" if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
+                     mirt.RT_BINNED: "k_rt_binned"}[st["mode_used"]]
             # algorithmic flops per launch = ray-triangle tests the launch executed x 60 flop per test as written in
             # the reference (brute force: rays x triangles; binned: candidates actually tested, counted in-kernel)
             algo_flop = tests_rank * FLOP_PER_TEST
@@ -261,8 +262,12 @@ def main():
                                "traffic": measured_traffic(args.workload, [kname]) if world == 1 else None,
                                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, bytes per launch)",
                                "tests_per_launch": int(tests_rank), "kernel_ms": round(kt, 5),
+                               "reference_tests_per_launch": int(rays_rank * len(tris)),
+                               "reference_equivalent_tflops": None if kt <= 0 else round(rays_rank * len(tris) * FLOP_PER_TEST / (kt * 1e-3) / 1e12, 3),
                                "note": "FP32 VALU-bound: not a contraction, so no MFMA; peak counts an FMA as 2 flop but bit-exact "
-                                       "parity forbids FMA contraction, so the reachable ceiling is 1/2 of peak"}
+                                       "parity forbids FMA contraction, so the reachable ceiling is 1/2 of peak. achieved = tests the "
+                                       "launch EXECUTED x 60 flop; reference_equivalent = the brute-force work of the reference "
+                                       "(rays x triangles x 60) over the same time"}
             algo_bytes = 4.0 * W * (y1 - y0) + 60.0 * len(tris)
             if kt > 0:
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": round(algo_bytes / (kt * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,

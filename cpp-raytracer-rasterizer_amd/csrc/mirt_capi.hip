@@ -25,6 +25,7 @@ struct RtTileFrame {
     BinFrameDesc cam;
     int tiles_x, tiles_y;
     int tiles_per_wave;
+    unsigned long long *clear_hits;
 };
 template <int TW> __global__ void k_rt_tile(const RtTileFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
@@ -78,7 +79,10 @@ struct Ctx {
     int light_tab_lights = 0;
     float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
     uint32_t *d_flags = nullptr;                 // [0] = unsafe flag
-    unsigned long long *d_hits = nullptr;        // HIT_SHARDS sharded hit counters (rt_common.hpp: count_hits)
+    unsigned long long *d_hits = nullptr;        // the hit-counter buffer of the current frame (one of d_hits2)
+    unsigned long long *d_hits2[2] = { nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
+    bool hits_clean[2] = { false, false };       // buffer is all zero (the tile kernel clears the other one itself)
+    int hits_cur = 0;
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
 
@@ -102,6 +106,8 @@ struct Ctx {
     uint64_t pending_primary = 0;
     int pending_nlights = 0;
     bool pending_is_rt = false;
+    bool pending_counted = false;                // the kernel counted its executed tests itself (tile / binned)
+    bool pending_empty = false;                  // the last ray-trace call rendered no rows (no counters to read)
 };
 
 Ctx g;
@@ -246,6 +252,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0);
     g.pending_nlights = nlights;
     g.stats.mode_used = MIRT_RT_BRUTE;
+    g.pending_empty = (y1 == y0);
+    g.pending_counted = false;
     if (y1 == y0) { call_end(); return MIRT_OK; }
 
     RtFrame f;
@@ -274,6 +282,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     f.pitch_words = pitch_bytes / 4;
     f.rgb = static_cast<float *>(d_rgb);
     f.index = static_cast<int32_t *>(d_index);
+    // hit counters: two buffers used alternately so that a kernel can clear the one the NEXT frame will use
+    g.hits_cur ^= 1;
+    g.d_hits = g.d_hits2[g.hits_cur];
     f.hit_count = g.d_hits;
 
     // The pre-reject filter is proven for finite, moderate operands only (rt_common.hpp); anything else
@@ -311,7 +322,12 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
         tf.tiles_per_wave = (int)std::min<long long>(16, std::max<long long>(1, ntiles / (4 * 2048)));
         const unsigned blocks = (unsigned)((ntiles + 4LL * tf.tiles_per_wave - 1) / (4LL * tf.tiles_per_wave));
-        HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
+        if (!g.hits_clean[g.hits_cur])
+            HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
+        g.hits_clean[g.hits_cur] = false;
+        g.pending_counted = true;
+        tf.clear_hits = g.d_hits2[g.hits_cur ^ 1];       // zeroed by this launch for the next frame: no memset node per frame
+        g.hits_clean[g.hits_cur ^ 1] = true;
         k_begin(MIRT_K_TRACE);
         if (tile_w == 8) hipLaunchKernelGGL(k_rt_tile<8>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
         else if (tile_w == 16) hipLaunchKernelGGL(k_rt_tile<16>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
@@ -325,6 +341,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     const size_t small_lds = 16 + (size_t)g.n * sizeof(OriginRow) * (2 + nlights);
     if (!binned && small_lds <= 48 * 1024) {
         HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
+        g.hits_clean[g.hits_cur] = false;
         k_begin(MIRT_K_TRACE);
         if (P == 2)
             hipLaunchKernelGGL(k_rt_small<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), small_lds, g.stream, f, safe ? 0 : 1);
@@ -338,6 +355,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
 
     HIP_TRY(hipMemcpyAsync(g.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
+    g.hits_clean[g.hits_cur] = false;
     HIP_TRY(hipMemcpyAsync(g.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
 
     k_begin(MIRT_K_PREP);
@@ -532,7 +550,12 @@ extern "C" int mirt_init(int device)
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_flags), 16));
     HIP_TRY(hipMemset(g.d_flags, 0, 16));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits2[i]), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
+        HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
+        g.hits_clean[i] = true;
+    }
+    g.d_hits = g.d_hits2[0];
     g.device = device;
     g.init = true;
     return MIRT_OK;
@@ -544,7 +567,7 @@ extern "C" void mirt_shutdown(void)
     (void)hipSetDevice(g.device);
     (void)hipStreamSynchronize(g.stream);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
-                     (void *)g.d_flags, (void *)g.d_hits, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
+                     (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
                      (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster);
@@ -733,7 +756,9 @@ extern "C" int mirt_get_stats(mirt_stats *out)
             if (g.profiling && g.ev_used[k] && hipEventElapsedTime(&ms, g.ev[EV_K0 + 2 * k], g.ev[EV_K0 + 2 * k + 1]) == hipSuccess)
                 g.stats.kernel_ms[k] = ms;
         }
-        if (g.pending_is_rt) {
+        if (g.pending_is_rt && g.pending_empty) {
+            g.stats.primary_rays = g.stats.shadow_rays = g.stats.tests = 0;
+        } else if (g.pending_is_rt) {
             static unsigned long long shard[HIT_SHARDS * HIT_SHARD_STRIDE];
             HIP_TRY(hipMemcpy(shard, g.d_hits, sizeof shard, hipMemcpyDeviceToHost));
             unsigned long long hits = 0, tests = 0;
@@ -741,7 +766,7 @@ extern "C" int mirt_get_stats(mirt_stats *out)
             g.stats.tests = tests;
             g.stats.primary_rays = g.pending_primary;
             g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
-            if (g.stats.mode_used == MIRT_RT_BRUTE)       // every ray tests every triangle
+            if (g.stats.mode_used == MIRT_RT_BRUTE && !g.pending_counted)      // every ray tests every triangle
                 g.stats.tests = (g.stats.primary_rays + g.stats.shadow_rays) * (uint64_t)g.n;
         }
         g.stats_pending = false;

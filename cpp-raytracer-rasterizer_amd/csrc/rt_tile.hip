@@ -23,6 +23,7 @@ struct RtTileFrame {
     BinFrameDesc cam;        // camera ray family (P0, Pu, Pv, dmax); bins are not used, only the edge functions
     int tiles_x, tiles_y;    // tiles in the band
     int tiles_per_wave;
+    unsigned long long *clear_hits;   // the OTHER hit-counter buffer: zeroed here for the next frame (saves a memset launch)
 };
 
 
@@ -107,6 +108,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
         cand = rect_may_hit(t, (float)x0, (float)min(x0 + TW - 1, f.W - 1), (float)y0, (float)min(y0 + TH - 1, f.y1 - 1));
     }
     unsigned long long pm = __ballot(cand);
+    unsigned ntests = ok ? (unsigned)__popcll(pm) : 0u;      // ray-triangle tests this lane runs (roofline bookkeeping)
 
     // d = (x - W/2, y - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
     const v3 d = V3((float)x - (float)f.W / 2.0f, (float)y - (float)f.H / 2.0f, f.focal);
@@ -151,6 +153,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
             bool sc = false;
             if (lane < n) sc = box_may_hit(tab[3 * lane], tab[3 * lane + 1], tab[3 * lane + 2], lo, hi);
             unsigned long long sm = __ballot(sc);
+            if (hit) ntests += (unsigned)__popcll(sm);
             bool live = hit;
             while (sm) {
                 const int j = __builtin_ctzll(sm);
@@ -174,6 +177,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
             avg = add3(avg, mul3(tcol, add3(Dl, ld3(f.indirect))));          // :584-591
         }
     }
+    count_tests(f, ntests);
     if (!ok) return;
     avg = div3s(avg, 1.0f);                                                  // :599
     const size_t px = (size_t)y * f.W + x;
@@ -218,6 +222,9 @@ __global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
         }
     }
     __syncthreads();
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < HIT_SHARDS * HIT_SHARD_STRIDE; i += 256) tf.clear_hits[i] = 0ull;
 
     const int wave = threadIdx.x >> 6;
     const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
