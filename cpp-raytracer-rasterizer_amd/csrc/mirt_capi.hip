@@ -85,6 +85,9 @@ struct Ctx {
     int hits_cur = 0;
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
+    int soft_samples = 1;                        // soft-shadow samples per light (1 = hard shadows)
+    int soft_npos = 0;
+    float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
 
     // binned ray tracing: frame descriptors, per-bin offsets / cursors, candidate entries
     BinFrameDesc *d_frames = nullptr;
@@ -242,15 +245,18 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
     if (mode != MIRT_RT_AUTO && mode != MIRT_RT_BRUTE && mode != MIRT_RT_BINNED) return fail(MIRT_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
 
-    if (nlights > g.light_tab_lights) {
-        if ((rc = dev_realloc(&g.d_light_tab, (size_t)nlights * g.n))) { g.light_tab_lights = 0; return rc; }
-        g.light_tab_lights = nlights;
+    const int light_positions = nlights * (g.soft_samples > 1 ? g.soft_samples : 1);    // shadow-ray origins
+    if (light_positions > MIRT_MAX_LIGHTS)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "%d lights x %d soft-shadow samples exceed %d light positions", nlights, g.soft_samples, MIRT_MAX_LIGHTS);
+    if (light_positions > g.light_tab_lights) {
+        if ((rc = dev_realloc(&g.d_light_tab, (size_t)light_positions * g.n))) { g.light_tab_lights = 0; return rc; }
+        g.light_tab_lights = light_positions;
     }
 
     call_begin();
     g.pending_is_rt = true;
     g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0);
-    g.pending_nlights = nlights;
+    g.pending_nlights = light_positions;
     g.stats.mode_used = MIRT_RT_BRUTE;
     g.pending_empty = (y1 == y0);
     g.pending_counted = false;
@@ -268,14 +274,25 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     f.focal = view->focal;
     f.W = view->width;
     f.H = view->height;
-    f.nlights = nlights;
+    // Light positions the shadow rays start from: the lights themselves, or with soft shadows `samples` jittered
+    // positions per light (randomPositions[k*SOFT_SHADOWS_SAMPLES + i], raytracer.cpp:286), each carrying the
+    // light's colour*intensity (:282) which light_term() divides by samples (:296).
+    const int samples = g.soft_samples > 1 ? g.soft_samples : 1;
+    const int npos = nlights * samples;
+    if (npos > MIRT_MAX_LIGHTS) return fail(MIRT_ERR_INVALID_ARGUMENT, "%d lights x %d soft-shadow samples exceed %d light positions", nlights, samples, MIRT_MAX_LIGHTS);
+    if (samples > 1 && npos > g.soft_npos) return fail(MIRT_ERR_INVALID_ARGUMENT, "%d jittered positions needed, %d were set (mirt_set_soft_shadows)", npos, g.soft_npos);
+    f.nlights = npos;
+    f.samples = samples;
     float origins[(1 + MIRT_MAX_LIGHTS) * 3];
     memcpy(origins, view->pos, 12);
-    for (int k = 0; k < nlights; k++) {
-        memcpy(f.lpos[k], lights[k].pos, 12);
-        memcpy(origins + 3 * (k + 1), lights[k].pos, 12);
-        for (int c = 0; c < 3; c++) f.lcol[k][c] = lights[k].color[c] * lights[k].intensity;   // raytracer.cpp:282
+    for (int j = 0; j < npos; j++) {
+        const int k = j / samples;
+        const float *pos = samples > 1 ? g.soft_pos + 3 * j : lights[k].pos;
+        memcpy(f.lpos[j], pos, 12);
+        memcpy(origins + 3 * (j + 1), pos, 12);
+        for (int c = 0; c < 3; c++) f.lcol[j][c] = lights[k].color[c] * lights[k].intensity;   // raytracer.cpp:282
     }
+    nlights = npos;            // from here on "lights" means light positions
     memcpy(f.indirect, indirect, 12);
     f.y0 = y0; f.y1 = y1; f.row_origin = row_origin;
     f.xrgb = static_cast<uint32_t *>(d_xrgb);
@@ -410,7 +427,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             d.Pu[(ax + 1) % 3] = 1.0f;
             d.Pv[(ax + 2) % 3] = 1.0f;
             d.rw[ax] = d.P0[ax]; d.ru[(ax + 1) % 3] = 1.0f; d.rv[(ax + 2) % 3] = 1.0f;   // g = m*(s e_k + u e_k1 + v e_k2)
-            memcpy(d.S, lights[k].pos, 12);
+            memcpy(d.S, f.lpos[k], 12);                       // light position k (jittered sample with soft shadows)
             d.dmax = 2.0f;
             d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / (float)cube_bins; d.dv = 2.0f / (float)cube_bins;
             d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
@@ -633,6 +650,20 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
 }
 
 extern "C" int mirt_scene_size(void) { return g.init ? g.n : 0; }
+
+extern "C" int mirt_set_soft_shadows(int samples, const float *positions, int npositions)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (samples <= 1) { g.soft_samples = 1; g.soft_npos = 0; return MIRT_OK; }
+    if (samples > MIRT_MAX_LIGHTS) return fail(MIRT_ERR_INVALID_ARGUMENT, "samples %d exceeds %d", samples, MIRT_MAX_LIGHTS);
+    if (!positions || npositions < samples || npositions > MIRT_MAX_LIGHTS)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "need between %d and %d jittered positions, got %d", samples, MIRT_MAX_LIGHTS, npositions);
+    memcpy(g.soft_pos, positions, sizeof(float) * 3 * (size_t)npositions);
+    g.soft_samples = samples;
+    g.soft_npos = npositions;
+    return MIRT_OK;
+}
 
 // ---- ray tracer -------------------------------------------------------------------------------------
 

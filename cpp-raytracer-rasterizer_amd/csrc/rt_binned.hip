@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
             }
             ntests += e - beg;
             result = add3(result, D);                      // (:319)
-            result2 = add3(result2, result);               // (:322)
+            if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
         }
         const v3 Dl = mul3(result2, tcol);                 // (:325-326)
         const v3 T = add3(Dl, ld3(f.indirect));            // (:584-586)

@@ -109,7 +109,8 @@ struct RtFrame {
     float rot[9];
     float focal;
     int W, H;
-    int nlights;
+    int nlights;                // light POSITIONS to trace shadow rays from: lights x samples (samples consecutive per light)
+    int samples;                // soft-shadow samples per light (SOFT_SHADOWS_SAMPLES, raytracer.cpp:41,272-275); 1 = off
     float lpos[MIRT_MAX_LIGHTS][3];
     float lcol[MIRT_MAX_LIGHTS][3];   // lights[k].color * lights[k].intensity (raytracer.cpp:282)
     float indirect[3];
@@ -183,7 +184,7 @@ __device__ __forceinline__ v3 light_term(const RtFrame &f, int k, v3 hit, v3 nDi
     const v3 L = ld3(f.lpos[k]);
     const float rr = distance3(hit, L);
     const float A = sphere_area(rr);
-    const v3 P = div3s(ld3(f.lcol[k]), 1.0f);          // lightColor /= (float)samples, samples == 1
+    const v3 P = div3s(ld3(f.lcol[k]), (float)f.samples);   // P = lightColor /= (float)samples (:296)
     const v3 rd = normalize3(sub3(L, hit));
     const v3 B = div3s(P, A);
     const float d = dot3(rd, nDir);

@@ -162,7 +162,7 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
 #pragma unroll
         for (int p = 0; p < P; p++) {
             result[p] = add3(result[p], D[p]);             // result += D   (:319)
-            result2[p] = add3(result2[p], result[p]);      // result2 += result, reference quirk (:322)
+            if ((k + 1) % f.samples == 0) result2[p] = add3(result2[p], result[p]);   // after each light's samples (:322)
         }
     }
 
@@ -306,7 +306,7 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 result[p] = add3(result[p], D[p]);                           // :319
-                result2[p] = add3(result2[p], result[p]);                    // :322
+                if ((k + 1) % f.samples == 0) result2[p] = add3(result2[p], result[p]);    // :322
             }
         }
     }
@@ -446,7 +446,7 @@ __device__ __forceinline__ void wave_body(const RtFrame &f)
             }
             if (occluded) D = V3(0.0f, 0.0f, 0.0f);                   // :313-314
             result = add3(result, D);                                 // :319
-            result2 = add3(result2, result);                          // :322
+            if ((k + 1) % f.samples == 0) result2 = add3(result2, result);                 // :322
         }
         const v3 Dl = mul3(result2, tcol);                            // :325-326
         avg = add3(avg, mul3(tcol, add3(Dl, ld3(f.indirect))));       // :584-591

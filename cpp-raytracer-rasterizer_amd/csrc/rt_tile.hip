@@ -170,7 +170,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
                 }
             }
             result = add3(result, D);                                        // :319
-            result2 = add3(result2, result);                                 // :322
+            if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // :322, after each light's samples
         }
         if (hit) {
             const v3 Dl = mul3(result2, tcol);                               // :325-326

@@ -1,6 +1,6 @@
 // demo_main.cpp -- the reference's main() loops (raytracer.cpp:113-178, rasteriser.cpp:101-149) on top of
 // mirt_draw.hpp, without SDL: a heap surface stands in for the window, one Update()+Draw() per "loop".
-//   demo_main rt|raster [width height [out.bmp [out.xrgb]]]
+//   demo_main rt|rtsoft|raster [width height [out.bmp [out.xrgb]]]      (rtsoft = ray tracer with SOFT_SHADOWS_ENABLED)
 // Writes a BMP screenshot (what SDL_SaveBMP(screen, "screenshot.bmp") does at :175/:147) and, optionally, the
 // raw XRGB words so tests can compare them with the oracle.
 #include "mirt_draw.hpp"
@@ -17,15 +17,17 @@ int main(int argc, char **argv)
     const char *bmp = argc > 4 ? argv[4] : "screenshot.bmp";
     const char *raw = argc > 5 ? argv[5] : nullptr;
     try {
-        check(mirt_init(0), "mirt_init");
         std::vector<uint32_t> pixels((size_t)W * H, 0u);
         Surface screen = { pixels.data(), W, H, W * 4 };            // InitializeSDL(W, H): 32-bit SWSURFACE
-        if (which == "rt") {
+        if (which == "rt" || which == "rtsoft") {
             RayTracer app;
+            app.SOFT_SHADOWS_ENABLED = which == "rtsoft";
             app.SCREEN_WIDTH = W; app.SCREEN_HEIGHT = H;
             app.focalLength = (float)H / 2.0f;                       // 250 for the reference's 500x500
             app.screen = screen;
-            app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // raytracer.cpp:116
+            app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // raytracer.cpp:116 (draws the soft-shadow jitter from
+                                                                     // rand(): do it before anything else can touch the stream)
+            check(mirt_init(0), "mirt_init");
             app.LoadTestModel();                                     // :149
             app.cameraRot[1][1] = 1.0f;                              // :162
             for (int loop = 0; loop < 2; loop++) {                   // while (NoQuitMessageSDL())
@@ -38,6 +40,7 @@ int main(int argc, char **argv)
             app.focalLength = (float)H;                              // 500 for the reference's 500x500
             app.screen = screen;
             app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // rasteriser.cpp:104
+            check(mirt_init(0), "mirt_init");
             app.LoadTestModel();                                     // :112
             app.cameraRot[1][1] = 1.01f;                             // :115 (sic)
             for (int loop = 0; loop < 2; loop++) {

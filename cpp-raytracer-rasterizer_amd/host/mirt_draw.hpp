@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -85,10 +86,21 @@ struct RayTracer {
     Surface screen = { nullptr, 0, 0, 0 };           // :76
     bool isUpdated = true;                           // :78
     bool scene_dirty = true;                         // set when `triangles` changes
+    bool SOFT_SHADOWS_ENABLED = false;               // :40
+    int SOFT_SHADOWS_SAMPLES = 16;                   // :41
+    vec3 randomPositions[256];                       // :84
 
-    void AddLight(vec3 position, vec3 color, float intensity)     // :180-193 (soft-shadow jitter is off-path)
+    static float RandomNumber() { return (float)(((double)std::rand() / (RAND_MAX)) - 0.5f); }   // :260-263
+
+    void AddLight(vec3 position, vec3 color, float intensity)     // :180-193
     {
         lights[NUM_LIGHTS].position = position; lights[NUM_LIGHTS].color = color; lights[NUM_LIGHTS].intensity = intensity;
+        for (int i = 0; i < SOFT_SHADOWS_SAMPLES; i++) {          // jittered copies for soft shadows (:186-190)
+            // the reference passes three RandomNumber() calls as arguments of one constructor call; g++ evaluates
+            // them right to left, which is spelled out here so the result does not depend on this file's compiler
+            const float rz = RandomNumber(), ry = RandomNumber(), rx = RandomNumber();
+            randomPositions[(NUM_LIGHTS * SOFT_SHADOWS_SAMPLES) + i] = vec3(position.x + (rx * 0.08f), position.y + (ry * 0.08f), position.z + (rz * 0.08f));
+        }
         NUM_LIGHTS++;
     }
     void LoadTestModel()                              // TestModel.h:51-192
@@ -108,6 +120,10 @@ struct RayTracer {
             scene_dirty = false;
         }
         const mirt_view view = make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
+        if (SOFT_SHADOWS_ENABLED)                                  // DirectLight's `samples` (:272-275)
+            check(mirt_set_soft_shadows(SOFT_SHADOWS_SAMPLES, &randomPositions[0].x, NUM_LIGHTS * SOFT_SHADOWS_SAMPLES), "mirt_set_soft_shadows");
+        else
+            check(mirt_set_soft_shadows(1, nullptr, 0), "mirt_set_soft_shadows");
         check(mirt_raytrace(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLight.x,
                             MIRT_RT_AUTO, screen.pixels, screen.pitch, nullptr, nullptr), "mirt_raytrace");
     }

@@ -20,7 +20,7 @@ KERNEL_NAMES = ("prep", "bin", "trace", "shade", "raster_setup", "raster_frag", 
 EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
-    "mirt_scene_soup", "mirt_cull", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
+    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats",
 )
 
@@ -64,6 +64,7 @@ def load():
     lib.mirt_scene_cornell.argtypes = [_vp]
     lib.mirt_scene_soup.argtypes = [C.c_uint32, C.c_int, C.c_float, _vp]
     lib.mirt_cull.argtypes = [_vp, C.c_int, C.POINTER(View), C.c_int, _vp]
+    lib.mirt_set_soft_shadows.argtypes = [C.c_int, _vp, C.c_int]
     lib.mirt_raytrace.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
     lib.mirt_raytrace_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _vp, C.c_int, _vp, _vp]
@@ -175,6 +176,15 @@ def scene_upload(tris, culled=None):
 def scene_set_culled(culled):
     culled = np.ascontiguousarray(culled, np.uint8)
     _check(load().mirt_scene_set_culled(_ptr(culled), len(culled)))
+
+
+def set_soft_shadows(samples, positions=None):
+    """samples <= 1 turns soft shadows off; otherwise positions is (nlights*samples, 3)."""
+    if samples <= 1:
+        _check(load().mirt_set_soft_shadows(1, None, 0))
+        return
+    p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    _check(load().mirt_set_soft_shadows(int(samples), _ptr(p), len(p)))
 
 
 # ---- render (host buffers) --------------------------------------------------------------------------

@@ -122,6 +122,13 @@ MIRT_API int mirt_scene_soup(uint32_t seed, int n, float s, float *tris15);
  * flags: bit0 = BACKFACE_CULLING_ENABLED, bit1 = FRUSTUM_CULLING_ENABLED (both default on, :25-26). */
 MIRT_API int mirt_cull(const float *tris15, int n, const mirt_view *view, int flags, uint8_t *culled);
 
+/* Soft shadows (SOFT_SHADOWS_ENABLED / SOFT_SHADOWS_SAMPLES / randomPositions, raytracer.cpp:40-41,84,186-190,
+ * 272-287): when samples > 1 every light k is replaced in DirectLight by `samples` jittered positions
+ * positions[(k*samples + i)*3 .. +2] with 1/samples of its power each.  The caller generates the positions (the
+ * reference draws them with rand() in AddLight; host/mirt_draw.hpp does the same).  samples <= 1 switches back to
+ * hard shadows.  lights x samples may not exceed MIRT_MAX_LIGHTS. */
+MIRT_API int mirt_set_soft_shadows(int samples, const float *positions, int npositions);
+
 /* ---- ray tracer: replaces Draw() + CalculateDOF() of raytracer.cpp:547-656 -------------------------- */
 
 /* One frame into host buffers.  out_xrgb (required) is the SDL surface's `pixels` (XRGB8888, the words

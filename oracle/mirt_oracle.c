@@ -288,18 +288,21 @@ static int closest_intersection(v3 start, v3 dir, const float *tris15, int n, hi
     return any;
 }
 
-/* DirectLight, raytracer.cpp:265-327 with SOFT_SHADOWS_ENABLED = false (samples = 1). */
-static v3 direct_light(const hit_t *i, const float *tris15, int n, const float *lights7, int nlights)
+/* DirectLight, raytracer.cpp:265-327.  samples == 1: SOFT_SHADOWS_ENABLED = false, position = lights[k].position;
+ * samples > 1: position = randomPositions[k*samples + counter] (:284-287), passed in as `jitter`. */
+static v3 direct_light(const hit_t *i, const float *tris15, int n, const float *lights7, int nlights,
+                       int samples, const float *jitter)
 {
     v3 result = V(0, 0, 0), result2 = V(0, 0, 0);
     const float *tri = tris15 + (size_t)15 * i->index;
     for (int k = 0; k < nlights; k++) {
+      for (int counter = 0; counter < samples; counter++) {                  /* :279 */
         const float *l = lights7 + 7 * k;
-        v3 position = ld3(l);
+        v3 position = samples != 1 ? ld3(jitter + 3 * (k * samples + counter)) : ld3(l);
         v3 lightColor = scale3(ld3(l + 3), l[6]);                              /* :282 */
         float r = distance3(i->position, position);                             /* :294 */
         float A = (float)(4 * M_PI * (double)(r * r));                          /* :295, double product narrowed */
-        v3 P = div3s(lightColor, 1.0f);                                         /* :296, /= (float)samples */
+        v3 P = div3s(lightColor, (float)samples);                               /* :296, lightColor /= (float)samples */
         v3 rDir = normalize3(sub3(position, i->position));                      /* :298 */
         v3 nDir = normalize3(ld3(tri + 9));                                     /* :300 */
         v3 B = div3s(P, A);                                                     /* :301 */
@@ -311,6 +314,7 @@ static v3 direct_light(const hit_t *i, const float *tris15, int n, const float *
         if (closest_intersection(position, neg3(rDir), tris15, n, &j))          /* :310 */
             if (j.distance < r * 0.99f) D = V(0, 0, 0);                         /* :313-314 */
         result = add3(result, D);                                               /* :319 */
+      }
         result2 = add3(result2, result);                                        /* :322, reference quirk E-3 */
     }
     return mul3(result2, ld3(tri + 12));                                        /* :325-326 */
@@ -333,11 +337,31 @@ static inline uint32_t pack_xrgb(v3 c) { return (chan8(c.x) << 16) | (chan8(c.y)
  * written (:618-620), the border keeps its previous value.  Any output may be NULL.
  * Returns the number of shadow rays traced (nlights per pixel whose primary ray hit).
  */
+ORACLE_API uint64_t mirt_oracle_raytrace_soft(const float *tris15, int n, const float *cam_pos, const float *rot9,
+                                              float focal, int W, int H, const float *lights7, int nlights,
+                                              int samples, const float *jitter,
+                                              const float *indirect, int y0, int y1, int threads,
+                                              float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
+                                              uint32_t *out_xrgb, int pitch_words);
+
 ORACLE_API uint64_t mirt_oracle_raytrace(const float *tris15, int n, const float *cam_pos, const float *rot9,
                                          float focal, int W, int H, const float *lights7, int nlights,
                                          const float *indirect, int y0, int y1, int threads,
                                          float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
                                          uint32_t *out_xrgb, int pitch_words)
+{
+    return mirt_oracle_raytrace_soft(tris15, n, cam_pos, rot9, focal, W, H, lights7, nlights, 1, NULL, indirect, y0, y1,
+                                     threads, out_rgb, out_index, out_dist, out_pos, out_xrgb, pitch_words);
+}
+
+/* The same with soft shadows: `samples` jittered positions per light (jitter[(k*samples+i)*3], what AddLight stores in
+ * randomPositions, raytracer.cpp:186-190); samples == 1 is the hard-shadow path.  Returns the shadow rays traced. */
+ORACLE_API uint64_t mirt_oracle_raytrace_soft(const float *tris15, int n, const float *cam_pos, const float *rot9,
+                                              float focal, int W, int H, const float *lights7, int nlights,
+                                              int samples, const float *jitter,
+                                              const float *indirect, int y0, int y1, int threads,
+                                              float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
+                                              uint32_t *out_xrgb, int pitch_words)
 {
     uint64_t nshadow = 0;
     const v3 camera = ld3(cam_pos), N = ld3(indirect);
@@ -356,12 +380,12 @@ ORACLE_API uint64_t mirt_oracle_raytrace(const float *tris15, int n, const float
             c.distance = FLT_MAX; c.index = -1; c.position = V(0, 0, 0);        /* Update() :335-339 */
             v3 avg = V(0, 0, 0);
             if (closest_intersection(camera, mat3_mul_vec(rot9, d), tris15, n, &c)) {   /* :580 */
-                v3 D = direct_light(&c, tris15, n, lights7, nlights);           /* :583 */
+                v3 D = direct_light(&c, tris15, n, lights7, nlights, samples, jitter);   /* :583 */
                 v3 T = add3(D, N);                                              /* :584-586 */
                 v3 p = ld3(tris15 + (size_t)15 * c.index + 12);                 /* :587 */
                 v3 R = mul3(p, T);                                              /* :588 */
                 avg = add3(avg, R);                                             /* :591 */
-                nshadow += (uint64_t)nlights;
+                nshadow += (uint64_t)nlights * (uint64_t)samples;
             }
             avg = div3s(avg, (float)(1 * 1));                                   /* :599 */
             if (out_rgb) st3(out_rgb + 3 * px, avg);                            /* :600 */
@@ -373,6 +397,21 @@ ORACLE_API uint64_t mirt_oracle_raytrace(const float *tris15, int n, const float
         }
     }
     return nshadow;
+}
+
+/* AddLight's jitter (raytracer.cpp:186-190) with RandomNumber() (:260-263): for each of `samples` positions three
+ * calls of ((double)rand()/RAND_MAX) - 0.5f, narrowed to float, times 0.08f, added to the light position.  Uses the
+ * C library's rand() stream exactly as the reference does (call srand(1) first for the reference's default state). */
+ORACLE_API void mirt_oracle_jitter(const float *light_pos, int samples, float *out)
+{
+    /* The three RandomNumber() calls are arguments of one constructor call, `vec3 randomPos(x + R*0.08f, y + R*0.08f,
+     * z + R*0.08f)` (:188); C++ leaves their order unspecified and g++ -- the compiler of the reference's Makefile --
+     * evaluates call arguments right to left, so z takes the first draw, then y, then x. */
+    for (int i = 0; i < samples; i++)
+        for (int c = 2; c >= 0; c--) {
+            float r = (float)(((double)rand() / (RAND_MAX)) - 0.5f);
+            out[3 * i + c] = light_pos[c] + (r * 0.08f);
+        }
 }
 
 /* ------------------------------------------------------------------------------------------ */

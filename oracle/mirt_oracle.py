@@ -43,6 +43,10 @@ class Oracle:
         lib.mirt_oracle_raytrace.restype = C.c_uint64
         lib.mirt_oracle_raytrace.argtypes = [f32p, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, _vp, C.c_int,
                                              f32p, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
+        lib.mirt_oracle_raytrace_soft.restype = C.c_uint64
+        lib.mirt_oracle_raytrace_soft.argtypes = [f32p, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, _vp, C.c_int,
+                                                  C.c_int, _vp, f32p, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
+        lib.mirt_oracle_jitter.argtypes = [f32p, C.c_int, f32p]
         lib.mirt_oracle_cull.argtypes = [f32p, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, C.c_int, _vp]
         lib.mirt_oracle_vertex_shader.argtypes = [f32p, f32p, f32p, C.c_float, C.c_int, C.c_int,
                                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), f32p]
@@ -78,9 +82,16 @@ class Oracle:
         return t
 
     # -- render paths --------------------------------------------------------------------------
+    def jitter(self, light_pos, samples):
+        """AddLight's soft-shadow positions for one light, drawn from the C library's rand() stream."""
+        out = np.zeros((samples, 3), np.float32)
+        self.lib.mirt_oracle_jitter(np.asarray(light_pos, np.float32), int(samples), out)
+        return out
+
     def raytrace(self, tris, cam_pos, rot9, focal, W, H, lights, indirect=(0.2, 0.2, 0.2), y0=0, y1=None,
-                 threads=0, want=("rgb", "index", "dist", "pos", "xrgb")):
-        """Returns dict(rgb, index, dist, pos, xrgb, nshadow); full-frame planes, band rows filled."""
+                 threads=0, want=("rgb", "index", "dist", "pos", "xrgb"), samples=1, jitter=None):
+        """Returns dict(rgb, index, dist, pos, xrgb, nshadow); full-frame planes, band rows filled.
+        samples > 1: soft shadows with `jitter` = (nlights*samples, 3) positions."""
         tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 15)
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 7)
         y1 = H if y1 is None else y1
@@ -91,9 +102,11 @@ class Oracle:
             "pos": np.zeros((H, W, 3), np.float32) if "pos" in want else None,
             "xrgb": np.zeros((H, W), np.uint32) if "xrgb" in want else None,
         }
-        ns = self.lib.mirt_oracle_raytrace(
+        jit = None if jitter is None else np.ascontiguousarray(jitter, np.float32)
+        ns = self.lib.mirt_oracle_raytrace_soft(
             tris, len(tris), np.asarray(cam_pos, np.float32), np.ascontiguousarray(rot9, np.float32), float(focal),
-            W, H, _ptr(lights) if len(lights) else None, len(lights), np.asarray(indirect, np.float32), y0, y1,
+            W, H, _ptr(lights) if len(lights) else None, len(lights), int(samples), _ptr(jit),
+            np.asarray(indirect, np.float32), y0, y1,
             threads, _ptr(out["rgb"]), _ptr(out["index"]), _ptr(out["dist"]), _ptr(out["pos"]), _ptr(out["xrgb"]), W)
         out["nshadow"] = int(ns)
         return out

@@ -131,3 +131,24 @@ def test_raster_column_zero_never_covered(rast):
     _, _, _, out = rast
     assert not (out["depth"][:, 0] > 0).any()
     assert (out["index"][out["depth"] > 0] >= 0).all() and (out["index"][out["depth"] == 0] == -1).all()
+
+
+def test_soft_shadow_jitter_follows_glibc_rand(oracle):
+    """AddLight's jitter (raytracer.cpp:186-190, 260-263): light + (float)(((double)rand()/RAND_MAX) - 0.5f) * 0.08f.
+    glibc's default stream (srand(1)) starts 1804289383, 846930886, 1681692777."""
+    import ctypes
+    ctypes.CDLL(None).srand(1)
+    j = oracle.jitter((0.0, -0.5, -0.7), 16)
+    # one constructor call takes the three draws; g++ evaluates its arguments right to left: z, y, x
+    want = [np.float32(l) + np.float32(np.float32(r / 2147483647.0 - 0.5) * np.float32(0.08))
+            for l, r in zip((0.0, -0.5, -0.7), (1681692777, 846930886, 1804289383))]
+    assert [float(x) for x in j[0]] == [float(x) for x in want]
+    assert j.shape == (16, 3) and np.all(np.abs(j - np.array([0.0, -0.5, -0.7], np.float32)) <= 0.0401)
+
+
+def test_soft_shadows_one_sample_equals_hard(oracle):
+    tris = oracle.cornell()
+    rot = oracle.rot_from_yaw(0.0, 1.0)
+    hard = oracle.raytrace(tris, (0, 0, -2), rot, 40.0, 80, 80, DEFAULT_LIGHT)
+    soft = oracle.raytrace(tris, (0, 0, -2), rot, 40.0, 80, 80, DEFAULT_LIGHT, samples=1, jitter=DEFAULT_LIGHT[:, 0:3])
+    assert np.array_equal(hard["rgb"].view(np.uint32), soft["rgb"].view(np.uint32))
