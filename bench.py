@@ -9,6 +9,7 @@ Prints ONE JSON line (rank 0).  Workloads (BASELINE.json `configs`):
     soup100k     (configs[2]) 100k random triangles, 1920x1080
     raster4k     (configs[3]) rasteriser, Cornell box, 3840x2160
     cornell500   (configs[0]) the reference's own 500x500 case
+    cornell1080soft16  configs[1] with the reference's 16-sample soft shadows switched on
     soup1m8k     (configs[4]) 1M random triangles, 7680x4320 (meant for 8 GPUs)
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the frame is split into N bands of
 rows; every rank renders its band and the XRGB bands are gathered on rank 0 over RCCL ("scaling": "strong").
@@ -35,6 +36,7 @@ WORKLOADS = {
     #  name         kind      scene                      W     H     cam            focal   rot11
     "cornell1080": ("rt", ("cornell",), 1920, 1080, (0, 0, -2), 540.0, 1.0),
     "cornell500": ("rt", ("cornell",), 500, 500, (0, 0, -2), 250.0, 1.0),
+    "cornell1080soft16": ("rt", ("cornell",), 1920, 1080, (0, 0, -2), 540.0, 1.0),   # + SOFT_SHADOWS_SAMPLES = 16
     "soup100k": ("rt", ("soup", 1, 100000, 0.05), 1920, 1080, (0, 0, -2), 540.0, 1.0),
     "soup1m8k": ("rt", ("soup", 2, 1000000, 0.02), 7680, 4320, (0, 0, -2), 2160.0, 1.0),
     "raster4k": ("raster", ("cornell",), 3840, 2160, (0, 0, -3), 2160.0, 1.01),
@@ -64,7 +66,7 @@ def measured_traffic(workload, kernel_prefixes):
     return tot or None
 
 
-def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0):
+def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, samples=1, jitter=None):
     """The oracle (CPU restatement, oracle/mirt_oracle.c) timed on this host's cores on a bounded sample of
     the same workload.  Test infrastructure: measured as a baseline, never used by the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -86,12 +88,13 @@ def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0):
     cores = min(cores, 64)                      # OpenMP over rows stops scaling long before 256 threads here
     centre = H // 2
     t0 = time.perf_counter()
-    r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=centre, y1=centre + 1, threads=cores, want=("xrgb",))
+    soft = dict(samples=samples, jitter=jitter)
+    r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=centre, y1=centre + 1, threads=cores, want=("xrgb",), **soft)
     probe = max(time.perf_counter() - t0, 1e-4)
     rows = int(max(cores, min(H, budget_s / probe)))
     if rows >= H:
         t0 = time.perf_counter()
-        r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, threads=cores, want=("xrgb",))
+        r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, threads=cores, want=("xrgb",), **soft)
         dt = time.perf_counter() - t0
         rays = W * H + r["nshadow"]
         sample = "full %dx%d frame" % (W, H)
@@ -100,7 +103,7 @@ def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0):
         ya = max(0, centre - rows // 2)
         yb = min(H, ya + rows)
         t0 = time.perf_counter()
-        r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=ya, y1=yb, threads=cores, want=("xrgb",))
+        r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=ya, y1=yb, threads=cores, want=("xrgb",), **soft)
         dt = time.perf_counter() - t0
         rays = W * (yb - ya) + r["nshadow"]
         sample = "rows %d..%d of %d (central band), per-ray rate" % (ya, yb - 1, H)
@@ -144,6 +147,13 @@ def main():
     culled = mirt.cull(tris, view, 3) if kind == "raster" else None
     mirt.scene_upload(tris, culled)
     mode = {"auto": mirt.RT_AUTO, "brute": mirt.RT_BRUTE, "binned": mirt.RT_BINNED}[args.mode]
+    soft_samples, soft_jitter = 1, None
+    if args.workload.endswith("soft16"):
+        # AddLight's jitter (raytracer.cpp:186-190): 16 positions, each coordinate light + U[-0.04, 0.04] (synthetic here:
+        # a fixed-seed numpy stream instead of the C library's rand())
+        soft_samples = 16
+        soft_jitter = (LIGHT[:, 0:3] + (np.random.RandomState(1).rand(16, 3).astype(np.float32) - np.float32(0.5)) * np.float32(0.08)).astype(np.float32)
+        mirt.set_soft_shadows(soft_samples, soft_jitter)
 
     steps = args.steps if args.steps is not None else (1000 if len(tris) < 1000 else 20)
     warmup = args.warmup if args.warmup is not None else (50 if len(tris) < 1000 else 3)
@@ -246,7 +256,7 @@ def main():
                 "metric": "Mrays/s (primary+shadow)", "unit": "Mrays/s", "dtype": "f32",
                 "value": round(rays_frame / (dt / steps) / 1e6, 3),
                 "config": {"workload": args.workload, "scene": "cornell-30" if scene[0] == "cornell" else "soup-%d-seed%d" % (scene[2], scene[1]),
-                           "triangles": int(len(tris)), "width": W, "height": H, "lights": 1,
+                           "triangles": int(len(tris)), "width": W, "height": H, "lights": 1, "soft_shadow_samples": soft_samples,
                            "primary_rays": W * H, "shadow_rays": int(shadow_frame), "mode": ["auto", "brute", "binned"][st["mode_used"]],
                            "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
             })
@@ -292,7 +302,7 @@ def main():
                                    "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, bytes per frame)",
                                    "algorithmic_bytes": int(algo_bytes), "frame_kernel_ms": round(tot, 5)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, tris, culled, W, H, cam, rot, focal)
+            out["cpu_baseline"] = cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, samples=soft_samples, jitter=soft_jitter)
         print(json.dumps(out), flush=True)
 
     if world > 1:

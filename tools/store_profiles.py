@@ -1,0 +1,24 @@
+"""tools/store_profiles.py <round tag, e.g. r01> -- copy what tools/collect_profiles.sh left in gpurun_out/ into profiles/."""
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+for f in glob.glob("gpurun_out/bench_*.json"):
+    if os.path.getsize(f) > 0:
+        shutil.copy(f, "profiles/%s_%s" % (tag, os.path.basename(f)))
+traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_hbm.sh: FETCH_SIZE and WRITE_SIZE in separate passes, "
+                       "KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); summarised by tools/pmc_summary.py. MI355X.",
+           "workloads": {}}
+for t in ("cornell1080", "soup100k", "raster4k"):
+    stats = sorted(glob.glob("gpurun_out/prof_%s/trace/*/*_kernel_stats.csv" % t), key=os.path.getmtime)
+    if stats:
+        shutil.copy(stats[-1], "profiles/%s_rocprof_%s_kernel_stats.csv" % (tag, t))
+    s = "gpurun_out/pmc_%s/summary.json" % t
+    if os.path.exists(s) and os.path.getsize(s) > 2:
+        traffic["workloads"][t] = json.load(open(s))
+if traffic["workloads"]:
+    json.dump(traffic, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
+print(sorted(os.listdir("profiles")))
