@@ -370,3 +370,49 @@ print("ok")
     finally:
         mirt.init(0)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+# ---- edge cases: tiny / ragged frames and kernel-selection boundaries ----------------------------------
+
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 3), (3, 3), (7, 5), (65, 9), (130, 3)])
+def test_rt_tiny_and_ragged_frames(oracle, W, H):
+    """Frames smaller than a tile / a wave, widths not a multiple of anything."""
+    _rt_compare(oracle, mirt.scene_cornell(), (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), max(H, 2) / 2.0, W, H, DEFAULT_LIGHT, mode=mirt.RT_AUTO)
+    tris = mirt.scene_soup(8, 700, 0.2)
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), max(H, 2) / 2.0, W, H, DEFAULT_LIGHT, mode=mirt.RT_BINNED)
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), max(H, 2) / 2.0, W, H, DEFAULT_LIGHT, mode=mirt.RT_BRUTE)
+
+
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 333, 334, 340, 1023, 1024, 1025, 2049])
+def test_rt_kernel_selection_boundaries(oracle, n):
+    """n = 64/65: tile-mask kernel vs LDS-resident kernel; 333/334: LDS-resident vs chunked brute force; 1024/1025:
+    one LDS chunk vs two; every choice must give the same bits."""
+    tris = mirt.scene_soup(100 + n, n, 0.3 if n < 400 else 0.15)
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.3, 1.0), 60.0, 150, 90, DEFAULT_LIGHT, mode=mirt.RT_BRUTE)
+
+
+def test_rt_no_lights_and_many_lights(oracle):
+    tris = mirt.scene_cornell()
+    rot = oracle.rot_from_yaw(0.0, 1.0)
+    _rt_compare(oracle, tris, (0, 0, -2), rot, 50.0, 100, 100, np.zeros((0, 7), np.float32), mode=mirt.RT_AUTO)
+    rng = np.random.default_rng(3)
+    lights = np.concatenate([rng.uniform(-0.8, 0.8, (32, 3)), rng.uniform(0.2, 1.0, (32, 3)), rng.uniform(1, 5, (32, 1))], axis=1).astype(np.float32)
+    _rt_compare(oracle, tris, (0, 0, -2), rot, 40.0, 80, 64, lights, mode=mirt.RT_AUTO)                      # MIRT_MAX_LIGHTS
+    _rt_compare(oracle, mirt.scene_soup(4, 2000, 0.15), (0, 0, -2), rot, 40.0, 80, 64, lights[:5], mode=mirt.RT_BINNED)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 2), (5, 3), (9, 70)])
+def test_raster_tiny_frames(oracle, W, H):
+    _raster_compare(oracle, mirt.scene_cornell(), (0, 0, -3), oracle.rot_from_yaw(0.0, 1.01), float(H), W, H, DEFAULT_LIGHT)
+
+
+def test_raster_triangles_crossing_the_camera_plane(oracle):
+    """Vertices at or behind the camera give infinite / out-of-contract screen coordinates: such triangles are skipped
+    by product and oracle alike, the rest must still match."""
+    tris = mirt.scene_soup(12, 400, 0.6)
+    _raster_compare(oracle, tris, (0.0, 0.0, -0.2), oracle.rot_from_yaw(0.2, 1.01), 120.0, 240, 160, DEFAULT_LIGHT, cull_flags=0)
+
+
+def test_raster_two_lights_and_band(oracle):
+    lights = np.array([[0, -0.5, -0.7, 1, 1, 1, 14], [0.5, 0.4, -1.5, 0.2, 0.9, 0.5, 9]], np.float32)
+    _raster_compare(oracle, mirt.scene_cornell(), (0.1, 0, -3), oracle.rot_from_yaw(0.15, 1.01), 300.0, 320, 300, lights)
