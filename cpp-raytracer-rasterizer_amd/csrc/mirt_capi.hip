@@ -86,6 +86,7 @@ struct Ctx {
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
     int soft_samples = 1;                        // soft-shadow samples per light (1 = hard shadows)
+    int aa = 1;                                  // realSamples of Draw(): AA_SAMPLES when AA_ENABLED, else 1
     int soft_npos = 0;
     float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
 
@@ -185,7 +186,7 @@ void call_end() { (void)hipEventRecord(g.ev[EV_CALL1], g.stream); g.stats_pendin
 
 // The camera ray family negD = -(R0*(x - W/2) + R1*(y - H/2) + R2*f) as a bin frame: (u, v) = pixel (x, y), bins =
 // 8x8-pixel tiles; also carries the inverse map for the bounding boxes (rt_binned.hpp).
-BinFrameDesc make_camera_frame(const mirt_view *view, int y0, int y1)
+BinFrameDesc make_camera_frame(const mirt_view *view, int y0, int y1, int aa)
 {
     const int W = view->width, H = view->height;
     BinFrameDesc c;
@@ -225,7 +226,8 @@ BinFrameDesc make_camera_frame(const mirt_view *view, int y0, int y1)
         }
         memcpy(c.S, view->pos, 12);
         c.ulo = 0.0f; c.vlo = 0.0f; c.du = (float)BIN_TILE; c.dv = (float)BIN_TILE;
-        c.pad_lo = 0.0f; c.pad_hi = -1.0f;                // bin i covers pixels 8i .. 8i+7 exactly
+        // bin i covers the rays of pixels 8i .. 8i+7: exactly their centres, or with supersampling half a pixel around them
+        c.pad_lo = aa > 1 ? -0.5f : 0.0f; c.pad_hi = aa > 1 ? -0.5f : -1.0f;
         c.nbu = (W + BIN_TILE - 1) / BIN_TILE; c.nbv = (H + BIN_TILE - 1) / BIN_TILE;
         c.j0 = y0 / BIN_TILE; c.j1 = (y1 + BIN_TILE - 1) / BIN_TILE;
         c.base = 0; c.tab = 0;
@@ -255,7 +257,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
 
     call_begin();
     g.pending_is_rt = true;
-    g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0);
+    g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0) * (uint64_t)((g.aa > 1 ? g.aa : 1) * (g.aa > 1 ? g.aa : 1));
     g.pending_nlights = light_positions;
     g.stats.mode_used = MIRT_RT_BRUTE;
     g.pending_empty = (y1 == y0);
@@ -283,6 +285,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     if (samples > 1 && npos > g.soft_npos) return fail(MIRT_ERR_INVALID_ARGUMENT, "%d jittered positions needed, %d were set (mirt_set_soft_shadows)", npos, g.soft_npos);
     f.nlights = npos;
     f.samples = samples;
+    f.aa = g.aa > 1 ? g.aa : 1;
     float origins[(1 + MIRT_MAX_LIGHTS) * 3];
     memcpy(origins, view->pos, 12);
     for (int j = 0; j < npos; j++) {
@@ -332,7 +335,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         RtTileFrame tf;
         memset(&tf, 0, sizeof tf);
         tf.f = f;
-        tf.cam = make_camera_frame(view, y0, y1);
+        tf.cam = make_camera_frame(view, y0, y1, g.aa);
         const int th = 64 / tile_w;
         tf.tiles_x = (view->width + tile_w - 1) / tile_w;
         tf.tiles_y = (rows + th - 1) / th;
@@ -380,7 +383,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
                        g.d_tris, g.n, g.d_origins, g.d_cam_tab, g.d_light_tab, g.d_flags);
     k_end(MIRT_K_PREP);
 
-    if (!binned && (long long)view->width * rows <= 4096 && g.n >= 1024) {
+    if (!binned && g.aa <= 1 && (long long)view->width * rows <= 4096 && g.n >= 1024) {
         // few rays, many triangles: one wave per ray, lanes over triangles, wavefront min-t reduce
         const long long nrays = (long long)view->width * rows;
         k_begin(MIRT_K_TRACE);
@@ -408,7 +411,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     BinFrameDesc frames[MAX_BIN_FRAMES];
     memset(frames, 0, sizeof frames);
     uint32_t nbins = 0;
-    frames[0] = make_camera_frame(view, y0, y1);
+    frames[0] = make_camera_frame(view, y0, y1, g.aa);
     nbins = (uint32_t)frames[0].nbu * frames[0].nbv;
     int nframes = 1;
     // light-cube resolution: 64 bins per face side measured best from 100k to 1M triangles (tools/sweep_cube.sh:
@@ -466,7 +469,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
     {
         auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
-        mix(view, sizeof *view); mix(origins, sizeof(float) * 3 * (1 + nlights)); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4); mix(&cube_bins, 4);
+        mix(view, sizeof *view); mix(origins, sizeof(float) * 3 * (1 + nlights)); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4); mix(&cube_bins, 4); mix(&g.aa, 4);
     }
 
     BinSet bs;
@@ -650,6 +653,15 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
 }
 
 extern "C" int mirt_scene_size(void) { return g.init ? g.n : 0; }
+
+extern "C" int mirt_set_antialiasing(int samples)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (samples > 8) return fail(MIRT_ERR_INVALID_ARGUMENT, "AA samples %d exceed 8 (the reference uses 3)", samples);
+    g.aa = samples > 1 ? samples : 1;
+    return MIRT_OK;
+}
 
 extern "C" int mirt_set_soft_shadows(int samples, const float *positions, int npositions)
 {

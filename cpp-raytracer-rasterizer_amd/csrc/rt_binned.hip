@@ -190,108 +190,118 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
     const int x = tx * BIN_TILE + (lane & 7), y = ty * BIN_TILE + (lane >> 3);
     const bool tile_ok = tx < bf.tiles_x && ty * BIN_TILE < f.y1;
     const bool ok = tile_ok && x < f.W && y >= f.y0 && y < f.y1;
+    if (!tile_ok) return;                                  // wave-uniform
     const v3 cam = ld3(f.cam);
+    const int rs = f.aa;                                   // realSamples (:549-554)
 
-    // d = (x - W/2, y - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
-    const v3 d = V3((float)x - (float)f.W / 2.0f, (float)y - (float)f.H / 2.0f, f.focal);
-    const v3 nd = neg3(mat3_mul_vec(f.rot, d));
-    float best_d = FLT_MAX;
+    const uint32_t cbin = bf.cam_base + (uint32_t)ty * bf.tiles_x + tx;
+    const uint32_t cbeg = bf.bins.bin_off[cbin], cend = bf.bins.bin_off[cbin + 1];
+
+    float best_d = FLT_MAX;                                // Update() reset (:335-339), once per frame
     int best_i = -1;
-    v3 pos = V3(0.0f, 0.0f, 0.0f);
+    v3 pos = V3(0.0f, 0.0f, 0.0f), avg = V3(0.0f, 0.0f, 0.0f);
     unsigned ntests = 0;
 
-    if (tile_ok) {
-        const uint32_t bin = bf.cam_base + (uint32_t)ty * bf.tiles_x + tx;
-        const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
-        if (ok) ntests = end - beg;
-        for (uint32_t base = beg; base < end; base += 64) {
-            const int cnt = (int)min(64u, end - base);
-            if (lane < cnt) {
-                const uint32_t idx = bf.bins.entries[base + lane];
-                const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
-                s_idx[wave][lane] = idx;
-                s_rows[wave][3 * lane] = src[0];
-                s_rows[wave][3 * lane + 1] = src[1];
-                s_rows[wave][3 * lane + 2] = src[2];
-            }
-            // wave-private LDS slice: the wave's own writes are visible to it after the LDS counter drains
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float4 n0 = s_rows[wave][0], n1 = s_rows[wave][1], n2 = s_rows[wave][2];
-            for (int j = 0; j < cnt; j++) {
-                const float4 r0 = n0, r1 = n1, r2 = n2;   // software pipeline: row j+1 loads while row j is tested
-                const int jn = min(j + 1, cnt - 1);
-                n0 = s_rows[wave][3 * jn]; n1 = s_rows[wave][3 * jn + 1]; n2 = s_rows[wave][3 * jn + 2];
-                const TestDots td = test_dots(r0, r1, r2, nd);
-                if (maybe_hit(td)) {
-                    const int idx = (int)s_idx[wave][j];
-                    v3 hp;
-                    float dist;
-                    if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, cam, &hp, &dist))
-                        if (closer(dist, idx, best_d, best_i)) { best_d = dist; best_i = idx; pos = hp; }
+    float y1 = aa_start(y, rs);                            // :566-569
+    for (int z = 0; z < rs; z++) {
+        float x1 = aa_start(x, rs);                        // :573-576
+        for (int z2 = 0; z2 < rs; z2++) {
+            // d = (x1 - W/2, y1 - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
+            const v3 d = V3(x1 - (float)f.W / 2.0f, y1 - (float)f.H / 2.0f, f.focal);
+            const v3 nd = neg3(mat3_mul_vec(f.rot, d));
+            // closest hit of THIS sub-ray among the tile's candidates (order-independent: min distance, max index) ...
+            float sd = FLT_MAX;
+            int si = -1;
+            v3 sp = V3(0.0f, 0.0f, 0.0f);
+            if (ok) ntests += cend - cbeg;
+            for (uint32_t base = cbeg; base < cend; base += 64) {
+                const int cnt = (int)min(64u, cend - base);
+                if (lane < cnt) {
+                    const uint32_t idx = bf.bins.entries[base + lane];
+                    const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
+                    s_idx[wave][lane] = idx;
+                    s_rows[wave][3 * lane] = src[0];
+                    s_rows[wave][3 * lane + 1] = src[1];
+                    s_rows[wave][3 * lane + 2] = src[2];
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-
-    const bool hit = ok && best_i >= 0;
-    {
-        const unsigned long long m = __popcll(__ballot(hit));
-        count_hits(f, m);
-    }
-    if (!__any(hit)) count_tests(f, ntests);      // no shadow rays in this wave: report now
-    if (!ok && !__any(hit)) return;
-
-    v3 avg = V3(0.0f, 0.0f, 0.0f);
-    if (hit) {
-        const float *t = f.tris15 + (size_t)15 * best_i;
-        const v3 nDir = normalize3(ld3(t + 9));            // (:300)
-        const v3 tcol = ld3(t + 12);
-        v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
-        for (int k = 0; k < f.nlights; k++) {
-            const v3 L = ld3(f.lpos[k]);
-            v3 rd;
-            float r;
-            v3 D = light_term(f, k, pos, nDir, &rd, &r);
-            const float thr = r * 0.99f;                   // (:313)
-            const uint32_t bin = cube_bin_of(rd, bf.light_base[k], bf.cube_bins);
-            const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
-            const OriginRow *tab = f.light_tab + (size_t)k * f.n;
-            uint32_t e = beg;
-            for (; e < end; e++) {
-                const uint32_t idx = bf.bins.entries[e];
-                const float4 *src = reinterpret_cast<const float4 *>(tab + idx);
-                const float4 r0 = src[0], r1 = src[1], r2 = src[2];
-                const TestDots td = test_dots(r0, r1, r2, rd);   // negD = rDir (:310, :229)
-                if (maybe_hit(td)) {
-                    v3 hp;
-                    float dist;
-                    if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, L, &hp, &dist) && dist < thr) {
-                        D = V3(0.0f, 0.0f, 0.0f);          // occluded (:313-314); any-hit is exact
-                        e++;
-                        break;
+                // wave-private LDS slice: the wave's own writes are visible to it after the LDS counter drains
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float4 n0 = s_rows[wave][0], n1 = s_rows[wave][1], n2 = s_rows[wave][2];
+                for (int j = 0; j < cnt; j++) {
+                    const float4 r0 = n0, r1 = n1, r2 = n2;   // software pipeline: row j+1 loads while row j is tested
+                    const int jn = min(j + 1, cnt - 1);
+                    n0 = s_rows[wave][3 * jn]; n1 = s_rows[wave][3 * jn + 1]; n2 = s_rows[wave][3 * jn + 2];
+                    const TestDots td = test_dots(r0, r1, r2, nd);
+                    if (maybe_hit(td)) {
+                        const int idx = (int)s_idx[wave][j];
+                        v3 hp;
+                        float dist;
+                        if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, cam, &hp, &dist))
+                            if (closer(dist, idx, sd, si)) { sd = dist; si = idx; sp = hp; }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            ntests += e - beg;
-            result = add3(result, D);                      // (:319)
-            if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
+            // ... merged into the pixel's running record exactly as the sequential `>=` sweep would (:243): the
+            // sub-ray's best replaces the record when it is at least as close (a later sub-ray wins exact ties)
+            const bool any = si >= 0;                      // ClosestIntersection's return value
+            if (any && best_d >= sd) { best_d = sd; best_i = si; pos = sp; }
+
+            const bool hit = ok && any;
+            count_hits(f, (unsigned long long)__popcll(__ballot(hit)));
+            if (hit) {
+                const float *t = f.tris15 + (size_t)15 * best_i;
+                const v3 nDir = normalize3(ld3(t + 9));            // (:300)
+                const v3 tcol = ld3(t + 12);
+                v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
+                for (int k = 0; k < f.nlights; k++) {
+                    const v3 L = ld3(f.lpos[k]);
+                    v3 rd;
+                    float r;
+                    v3 D = light_term(f, k, pos, nDir, &rd, &r);
+                    const float thr = r * 0.99f;                   // (:313)
+                    const uint32_t bin = cube_bin_of(rd, bf.light_base[k], bf.cube_bins);
+                    const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
+                    const OriginRow *tab = f.light_tab + (size_t)k * f.n;
+                    uint32_t e = beg;
+                    for (; e < end; e++) {
+                        const uint32_t idx = bf.bins.entries[e];
+                        const float4 *src = reinterpret_cast<const float4 *>(tab + idx);
+                        const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+                        const TestDots td = test_dots(r0, r1, r2, rd);   // negD = rDir (:310, :229)
+                        if (maybe_hit(td)) {
+                            v3 hp;
+                            float dist;
+                            if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, L, &hp, &dist) && dist < thr) {
+                                D = V3(0.0f, 0.0f, 0.0f);          // occluded (:313-314); any-hit is exact
+                                e++;
+                                break;
+                            }
+                        }
+                    }
+                    ntests += e - beg;
+                    result = add3(result, D);                      // (:319)
+                    if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
+                }
+                const v3 Dl = mul3(result2, tcol);                 // (:325-326)
+                const v3 T = add3(Dl, ld3(f.indirect));            // (:584-586)
+                avg = add3(avg, mul3(tcol, T));                    // (:587-591)
+                x1 += aa_step(rs);                                 // (:593) only after a hit
+            }
         }
-        const v3 Dl = mul3(result2, tcol);                 // (:325-326)
-        const v3 T = add3(Dl, ld3(f.indirect));            // (:584-586)
-        avg = add3(avg, mul3(tcol, T));                    // (:587-591)
+        y1 += aa_step(rs);                                         // (:596)
     }
-    if (__any(hit)) count_tests(f, ntests);
+    count_tests(f, ntests);
     if (!ok) return;
-    avg = div3s(avg, 1.0f);                                // (:599)
+    avg = div3s(avg, (float)(rs * rs));                            // (:599)
     const size_t px = (size_t)y * f.W + x;
     if (f.rgb) st3(f.rgb + 3 * px, avg);
     if (f.index) f.index[px] = best_i;
-    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)    // (:618-620)
+    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)            // (:618-620)
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
 

@@ -110,6 +110,7 @@ struct RtFrame {
     float focal;
     int W, H;
     int nlights;                // light POSITIONS to trace shadow rays from: lights x samples (samples consecutive per light)
+    int aa;                     // realSamples of Draw(): AA_SAMPLES when AA_ENABLED, else 1 (raytracer.cpp:37-38,549-554)
     int samples;                // soft-shadow samples per light (SOFT_SHADOWS_SAMPLES, raytracer.cpp:41,272-275); 1 = off
     float lpos[MIRT_MAX_LIGHTS][3];
     float lcol[MIRT_MAX_LIGHTS][3];   // lights[k].color * lights[k].intensity (raytracer.cpp:282)
@@ -144,6 +145,12 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
 }
+
+// Sub-ray stepping of Draw()'s supersampling loops (raytracer.cpp:566-596): y1/x1 start at the pixel centre, or half a
+// pixel before it when realSamples > 1, and advance by 1/(realSamples-1).  (With realSamples == 1 that increment is
+// 1/0 = +inf, exactly as in the reference; the value is never used again.)
+__device__ __forceinline__ float aa_start(int c, int rs) { return rs > 1 ? (float)c - 0.5f : (float)c; }
+__device__ __forceinline__ float aa_step(int rs) { return 1.0f / (float)(rs - 1); }
 
 // ---- wavefront min-t primitive ------------------------------------------------------------------------
 // The reference's sequential closest-hit update, `if (closest.distance >= distance)` in index order

@@ -46,146 +46,166 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
     const bool row_ok = y < f.y1;
     const v3 cam = ld3(f.cam);
     const float halfW = (float)f.W / 2.0f, halfH = (float)f.H / 2.0f;
+    const int rs = f.aa;                                  // realSamples (:549-554)
 
     int xs[P];
     bool ok[P];
-    v3 nd[P], pos[P];
-    float best_d[P];
+    v3 pos[P], avg[P];
+    float best_d[P], x1[P];
     int best_i[P];
 #pragma unroll
     for (int p = 0; p < P; p++) {
         xs[p] = ((int)blockIdx.x * P + p) * 64 + lane;
         ok[p] = row_ok && xs[p] < f.W;
-        // d = (x - W/2, y - H/2, focalLength); dir = cameraRot * d   (raytracer.cpp:579-580)
-        const v3 d = V3((float)xs[p] - halfW, (float)y - halfH, f.focal);
-        nd[p] = neg3(mat3_mul_vec(f.rot, d));            // negD = -dir (:229)
-        best_d[p] = FLT_MAX;                              // Update() reset (:335-339)
+        best_d[p] = FLT_MAX;                              // Update() reset (:335-339), once per frame
         best_i[p] = -1;
-        pos[p] = V3(0.0f, 0.0f, 0.0f);
+        pos[p] = avg[p] = V3(0.0f, 0.0f, 0.0f);
     }
 
-    // ---------------- primary rays: closest hit, ties -> later index (:243) ----------------
-    for (int base = 0; base < f.n; base += RT_CHUNK) {
-        const int cnt = min(RT_CHUNK, f.n - base);
-        __syncthreads();
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + base);
-            for (int k = threadIdx.x; k < cnt * 3; k += 256) s_tab[k] = src[k];
-        }
-        __syncthreads();
-        float4 n0 = s_tab[0], n1 = s_tab[1], n2 = s_tab[2];
-        for (int j = 0; j < cnt; j++) {
-            const float4 r0 = n0, r1 = n1, r2 = n2;       // software pipeline: row j+1 loads while row j is tested
-            const int jn = min(j + 1, cnt - 1);
-            n0 = s_tab[3 * jn]; n1 = s_tab[3 * jn + 1]; n2 = s_tab[3 * jn + 2];
+    float y1 = aa_start(y, rs);                           // :566-569
+    for (int z = 0; z < rs; z++) {
+#pragma unroll
+        for (int p = 0; p < P; p++) x1[p] = aa_start(xs[p], rs);          // :573-576
+        for (int z2 = 0; z2 < rs; z2++) {
+            v3 nd[P];
+            bool any[P];
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const TestDots d = test_dots(r0, r1, r2, nd[p]);
-                if (!FILTER || maybe_hit(d)) {
-                    v3 hp;
-                    float dist;
-                    if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), cam, &hp, &dist)) {
-                        if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = base + j; pos[p] = hp; }
-                    }
+                // d = (x1 - W/2, y1 - H/2, focalLength); dir = cameraRot * d   (raytracer.cpp:579-580)
+                const v3 d = V3(x1[p] - halfW, y1 - halfH, f.focal);
+                nd[p] = neg3(mat3_mul_vec(f.rot, d));     // negD = -dir (:229)
+                any[p] = false;
+            }
+
+            // ---------------- primary sub-ray: closest hit so far, ties -> later index (:243) ----------------
+            for (int base = 0; base < f.n; base += RT_CHUNK) {
+                const int cnt = min(RT_CHUNK, f.n - base);
+                __syncthreads();
+                {
+                    const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + base);
+                    for (int k = threadIdx.x; k < cnt * 3; k += 256) s_tab[k] = src[k];
                 }
-            }
-        }
-    }
-
-    // ---------------- DirectLight: one shadow ray per light per hit pixel ----------------
-    v3 result[P], result2[P], nDir[P], tcol[P];
-    bool hit[P];
+                __syncthreads();
+                float4 n0 = s_tab[0], n1 = s_tab[1], n2 = s_tab[2];
+                for (int j = 0; j < cnt; j++) {
+                    const float4 r0 = n0, r1 = n1, r2 = n2;       // software pipeline: row j+1 loads while row j is tested
+                    const int jn = min(j + 1, cnt - 1);
+                    n0 = s_tab[3 * jn]; n1 = s_tab[3 * jn + 1]; n2 = s_tab[3 * jn + 2];
 #pragma unroll
-    for (int p = 0; p < P; p++) {
-        hit[p] = ok[p] && best_i[p] >= 0;
-        result[p] = result2[p] = V3(0.0f, 0.0f, 0.0f);
-        const float *t = f.tris15 + (size_t)15 * (best_i[p] >= 0 ? best_i[p] : 0);
-        nDir[p] = normalize3(ld3(t + 9));                 // glm::normalize(triangles[idx].normal) (:300)
-        tcol[p] = ld3(t + 12);
-    }
-    {
-        unsigned long long m = 0;
-#pragma unroll
-        for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
-        count_hits(f, m);
-    }
-
-    for (int k = 0; k < f.nlights; k++) {
-        const v3 L = ld3(f.lpos[k]);
-        v3 D[P], rd[P];
-        float thr[P];
-        bool live[P];      // still needs shadow testing
-        bool any_live = false;
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            float r;
-            D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
-            thr[p] = r * 0.99f;                            // j.distance < r*0.99f (:313)
-            live[p] = hit[p];
-            any_live |= live[p];
-        }
-        const OriginRow *tab = f.light_tab + (size_t)k * f.n;
-        // every wave of the block must take part in the staging barriers, so the chunk loop is
-        // unconditional; a wave with nothing left to test just skips the inner loop.
-        for (int base = 0; base < f.n; base += RT_CHUNK) {
-            const int cnt = min(RT_CHUNK, f.n - base);
-            __syncthreads();
-            {
-                const float4 *src = reinterpret_cast<const float4 *>(tab + base);
-                for (int q = threadIdx.x; q < cnt * 3; q += 256) s_tab[q] = src[q];
-            }
-            __syncthreads();
-            if (!__any(any_live)) continue;
-            float4 n0 = s_tab[0], n1 = s_tab[1], n2 = s_tab[2];
-            for (int j = 0; j < cnt; j++) {
-                const float4 r0 = n0, r1 = n1, r2 = n2;
-                const int jn = min(j + 1, cnt - 1);
-                n0 = s_tab[3 * jn]; n1 = s_tab[3 * jn + 1]; n2 = s_tab[3 * jn + 2];
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    // shadow ray: start = light, dir = -rDir, so negD = rDir (:310, :229)
-                    const TestDots d = test_dots(r0, r1, r2, rd[p]);
-                    if (live[p] && (!FILTER || maybe_hit(d))) {
-                        v3 hp;
-                        float dist;
-                        if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), L, &hp, &dist)) {
-                            // min over accepted hits < thr  <=>  some accepted hit < thr (any-hit is exact)
-                            if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);
+                    for (int p = 0; p < P; p++) {
+                        const TestDots d = test_dots(r0, r1, r2, nd[p]);
+                        if (!FILTER || maybe_hit(d)) {
+                            v3 hp;
+                            float dist;
+                            if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), cam, &hp, &dist)) {
+                                any[p] = true;
+                                if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = base + j; pos[p] = hp; }
+                            }
                         }
                     }
                 }
             }
-            any_live = false;
+
+            // ---------------- DirectLight: one shadow ray per light position per sub-ray that hit ----------------
+            v3 result[P], result2[P], nDir[P], tcol[P];
+            bool hit[P];
 #pragma unroll
-            for (int p = 0; p < P; p++) any_live |= live[p];
-        }
+            for (int p = 0; p < P; p++) {
+                hit[p] = ok[p] && any[p];
+                result[p] = result2[p] = V3(0.0f, 0.0f, 0.0f);
+                const float *t = f.tris15 + (size_t)15 * (best_i[p] >= 0 ? best_i[p] : 0);
+                nDir[p] = normalize3(ld3(t + 9));         // glm::normalize(triangles[idx].normal) (:300)
+                tcol[p] = ld3(t + 12);
+            }
+            {
+                unsigned long long m = 0;
 #pragma unroll
-        for (int p = 0; p < P; p++) {
-            result[p] = add3(result[p], D[p]);             // result += D   (:319)
-            if ((k + 1) % f.samples == 0) result2[p] = add3(result2[p], result[p]);   // after each light's samples (:322)
+                for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
+                count_hits(f, m);
+            }
+
+            for (int k = 0; k < f.nlights; k++) {
+                const v3 L = ld3(f.lpos[k]);
+                v3 D[P], rd[P];
+                float thr[P];
+                bool live[P];      // still needs shadow testing
+                bool any_live = false;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    float r;
+                    D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
+                    thr[p] = r * 0.99f;                    // j.distance < r*0.99f (:313)
+                    live[p] = hit[p];
+                    any_live |= live[p];
+                }
+                const OriginRow *tab = f.light_tab + (size_t)k * f.n;
+                // every wave of the block must take part in the staging barriers, so the chunk loop is
+                // unconditional; a wave with nothing left to test just skips the inner loop.
+                for (int base = 0; base < f.n; base += RT_CHUNK) {
+                    const int cnt = min(RT_CHUNK, f.n - base);
+                    __syncthreads();
+                    {
+                        const float4 *src = reinterpret_cast<const float4 *>(tab + base);
+                        for (int q = threadIdx.x; q < cnt * 3; q += 256) s_tab[q] = src[q];
+                    }
+                    __syncthreads();
+                    if (!__any(any_live)) continue;
+                    float4 n0 = s_tab[0], n1 = s_tab[1], n2 = s_tab[2];
+                    for (int j = 0; j < cnt; j++) {
+                        const float4 r0 = n0, r1 = n1, r2 = n2;
+                        const int jn = min(j + 1, cnt - 1);
+                        n0 = s_tab[3 * jn]; n1 = s_tab[3 * jn + 1]; n2 = s_tab[3 * jn + 2];
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            // shadow ray: start = light, dir = -rDir, so negD = rDir (:310, :229)
+                            const TestDots d = test_dots(r0, r1, r2, rd[p]);
+                            if (live[p] && (!FILTER || maybe_hit(d))) {
+                                v3 hp;
+                                float dist;
+                                if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), L, &hp, &dist)) {
+                                    // min over accepted hits < thr  <=>  some accepted hit < thr (any-hit is exact)
+                                    if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);
+                                }
+                            }
+                        }
+                    }
+                    any_live = false;
+#pragma unroll
+                    for (int p = 0; p < P; p++) any_live |= live[p];
+                }
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    result[p] = add3(result[p], D[p]);             // result += D   (:319)
+                    if ((k + 1) % f.samples == 0) result2[p] = add3(result2[p], result[p]);   // after each light's samples (:322)
+                }
+            }
+
+            const v3 N = ld3(f.indirect);
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                if (hit[p]) {
+                    const v3 Dl = mul3(result2[p], tcol[p]);       // DirectLight returns result2 * color (:325-326)
+                    const v3 T = add3(Dl, N);                      // (:584-586)
+                    avg[p] = add3(avg[p], mul3(tcol[p], T));       // (:587-591)
+                    x1[p] += aa_step(rs);                          // (:593) only after a hit
+                }
+            }
         }
+        y1 += aa_step(rs);                                         // (:596)
     }
 
-    // ---------------- shade + resolve ----------------
-    const v3 N = ld3(f.indirect);
+    // ---------------- resolve ----------------
 #pragma unroll
     for (int p = 0; p < P; p++) {
         if (!ok[p]) continue;
-        v3 avg = V3(0.0f, 0.0f, 0.0f);
-        if (hit[p]) {
-            const v3 Dl = mul3(result2[p], tcol[p]);       // DirectLight returns result2 * color (:325-326)
-            const v3 T = add3(Dl, N);                      // (:584-586)
-            const v3 R = mul3(tcol[p], T);                 // (:587-588)
-            avg = add3(avg, R);                            // (:591)
-        }
-        avg = div3s(avg, 1.0f);                            // /= realSamples^2 (:599)
+        const v3 out = div3s(avg[p], (float)(rs * rs));            // /= realSamples^2 (:599)
         const int x = xs[p];
         const size_t px = (size_t)y * f.W + x;
-        if (f.rgb) st3(f.rgb + 3 * px, avg);
+        if (f.rgb) st3(f.rgb + 3 * px, out);
         if (f.index) f.index[px] = best_i[p];
         // CalculateDOF draws interior pixels only (:618-620); the border keeps its old value
         if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)
-            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(out);
     }
 }
 
@@ -220,114 +240,133 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
     const v3 cam = ld3(f.cam);
     const float halfW = (float)f.W / 2.0f, halfH = (float)f.H / 2.0f;
     const int n = f.n;
+    const int rs = f.aa;                                                     // realSamples (:549-554)
 
     int xs[P];
     bool ok[P];
-    v3 nd[P], pos[P];
-    float best_d[P];
+    v3 pos[P], avg[P];
+    float best_d[P], x1[P];
     int best_i[P];
 #pragma unroll
     for (int p = 0; p < P; p++) {
         xs[p] = ((int)blockIdx.x * P + p) * 64 + lane;
         ok[p] = xs[p] < f.W;
-        const v3 d = V3((float)xs[p] - halfW, (float)y - halfH, f.focal);   // raytracer.cpp:579
-        nd[p] = neg3(mat3_mul_vec(f.rot, d));                                // :580, :229
-        best_d[p] = FLT_MAX;
+        best_d[p] = FLT_MAX;                                                 // Update() reset, once per frame
         best_i[p] = -1;
-        pos[p] = V3(0.0f, 0.0f, 0.0f);
-    }
-    // software pipeline: row j+1 is on its way from LDS while row j is tested
-    float4 n0 = s_cam[0], n1 = s_cam[1], n2 = s_cam[2];
-    for (int j = 0; j < n; j++) {
-        const float4 r0 = n0, r1 = n1, r2 = n2;
-        const int jn = min(j + 1, n - 1);
-        n0 = s_cam[3 * jn]; n1 = s_cam[3 * jn + 1]; n2 = s_cam[3 * jn + 2];
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const TestDots d = test_dots(r0, r1, r2, nd[p]);
-            if (!FILTER || maybe_hit(d)) {
-                v3 hp;
-                float dist;
-                if (exact_hit_lds(d, r0.w, s_geo + 3 * j, cam, &hp, &dist))
-                    if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = j; pos[p] = hp; }   // :243-247
-            }
-        }
+        pos[p] = avg[p] = V3(0.0f, 0.0f, 0.0f);
     }
 
-    bool hit[P];
-    bool any_hit = false;
+    float y1 = aa_start(y, rs);                                              // :566-569
+    for (int z = 0; z < rs; z++) {
 #pragma unroll
-    for (int p = 0; p < P; p++) { hit[p] = ok[p] && best_i[p] >= 0; any_hit |= hit[p]; }
-    {
-        unsigned long long m = 0;
-#pragma unroll
-        for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
-        count_hits(f, m);
-    }
-
-    v3 result[P], result2[P], nDir[P], tcol[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        result[p] = result2[p] = V3(0.0f, 0.0f, 0.0f);
-        const float *t = f.tris15 + (size_t)15 * (best_i[p] >= 0 ? best_i[p] : 0);
-        nDir[p] = normalize3(ld3(t + 9));                                    // :300
-        tcol[p] = ld3(t + 12);
-    }
-    if (__any(any_hit)) {
-        for (int k = 0; k < f.nlights; k++) {
-            const v3 L = ld3(f.lpos[k]);
-            const float4 *tab = s_light + (size_t)3 * n * k;
-            v3 D[P], rd[P];
-            float thr[P];
-            bool live[P];
+        for (int p = 0; p < P; p++) x1[p] = aa_start(xs[p], rs);            // :573-576
+        for (int z2 = 0; z2 < rs; z2++) {
+            v3 nd[P];
+            bool any[P];
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                float r;
-                D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
-                thr[p] = r * 0.99f;                                          // :313
-                live[p] = hit[p];
+                const v3 d = V3(x1[p] - halfW, y1 - halfH, f.focal);        // raytracer.cpp:579
+                nd[p] = neg3(mat3_mul_vec(f.rot, d));                        // :580, :229
+                any[p] = false;
             }
-            float4 n0 = tab[0], n1 = tab[1], n2 = tab[2];
+            // software pipeline: row j+1 is on its way from LDS while row j is tested
+            float4 n0 = s_cam[0], n1 = s_cam[1], n2 = s_cam[2];
             for (int j = 0; j < n; j++) {
                 const float4 r0 = n0, r1 = n1, r2 = n2;
                 const int jn = min(j + 1, n - 1);
-                n0 = tab[3 * jn]; n1 = tab[3 * jn + 1]; n2 = tab[3 * jn + 2];
+                n0 = s_cam[3 * jn]; n1 = s_cam[3 * jn + 1]; n2 = s_cam[3 * jn + 2];
 #pragma unroll
                 for (int p = 0; p < P; p++) {
-                    const TestDots d = test_dots(r0, r1, r2, rd[p]);         // negD = rDir (:310, :229)
-                    if (live[p] && (!FILTER || maybe_hit(d))) {
+                    const TestDots d = test_dots(r0, r1, r2, nd[p]);
+                    if (!FILTER || maybe_hit(d)) {
                         v3 hp;
                         float dist;
-                        if (exact_hit_lds(d, r0.w, s_geo + 3 * j, L, &hp, &dist))
-                            if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);   // :313-314
+                        if (exact_hit_lds(d, r0.w, s_geo + 3 * j, cam, &hp, &dist)) {
+                            any[p] = true;
+                            if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = j; pos[p] = hp; }   // :243-247
+                        }
                     }
                 }
             }
+
+            bool hit[P];
+            bool any_hit = false;
+#pragma unroll
+            for (int p = 0; p < P; p++) { hit[p] = ok[p] && any[p]; any_hit |= hit[p]; }
+            {
+                unsigned long long m = 0;
+#pragma unroll
+                for (int p = 0; p < P; p++) m += __popcll(__ballot(hit[p]));
+                count_hits(f, m);
+            }
+            if (!__any(any_hit)) continue;
+
+            v3 result[P], result2[P], nDir[P], tcol[P];
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                result[p] = add3(result[p], D[p]);                           // :319
-                if ((k + 1) % f.samples == 0) result2[p] = add3(result2[p], result[p]);    // :322
+                result[p] = result2[p] = V3(0.0f, 0.0f, 0.0f);
+                const float *t = f.tris15 + (size_t)15 * (best_i[p] >= 0 ? best_i[p] : 0);
+                nDir[p] = normalize3(ld3(t + 9));                            // :300
+                tcol[p] = ld3(t + 12);
+            }
+            for (int k = 0; k < f.nlights; k++) {
+                const v3 L = ld3(f.lpos[k]);
+                const float4 *tab = s_light + (size_t)3 * n * k;
+                v3 D[P], rd[P];
+                float thr[P];
+                bool live[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    float r;
+                    D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
+                    thr[p] = r * 0.99f;                                      // :313
+                    live[p] = hit[p];
+                }
+                float4 m0 = tab[0], m1 = tab[1], m2 = tab[2];
+                for (int j = 0; j < n; j++) {
+                    const float4 r0 = m0, r1 = m1, r2 = m2;
+                    const int jn = min(j + 1, n - 1);
+                    m0 = tab[3 * jn]; m1 = tab[3 * jn + 1]; m2 = tab[3 * jn + 2];
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const TestDots d = test_dots(r0, r1, r2, rd[p]);     // negD = rDir (:310, :229)
+                        if (live[p] && (!FILTER || maybe_hit(d))) {
+                            v3 hp;
+                            float dist;
+                            if (exact_hit_lds(d, r0.w, s_geo + 3 * j, L, &hp, &dist))
+                                if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);   // :313-314
+                        }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    result[p] = add3(result[p], D[p]);                       // :319
+                    if ((k + 1) % f.samples == 0) result2[p] = add3(result2[p], result[p]);    // :322
+                }
+            }
+            const v3 N = ld3(f.indirect);
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                if (hit[p]) {
+                    const v3 Dl = mul3(result2[p], tcol[p]);                 // :325-326
+                    avg[p] = add3(avg[p], mul3(tcol[p], add3(Dl, N)));       // :584-591
+                    x1[p] += aa_step(rs);                                    // :593, only after a hit
+                }
             }
         }
+        y1 += aa_step(rs);                                                   // :596
     }
 
-    const v3 N = ld3(f.indirect);
 #pragma unroll
     for (int p = 0; p < P; p++) {
         if (!ok[p]) continue;
-        v3 avg = V3(0.0f, 0.0f, 0.0f);
-        if (hit[p]) {
-            const v3 Dl = mul3(result2[p], tcol[p]);                         // :325-326
-            const v3 T = add3(Dl, N);                                        // :584-586
-            avg = add3(avg, mul3(tcol[p], T));                               // :587-591
-        }
-        avg = div3s(avg, 1.0f);                                              // :599
+        const v3 out = div3s(avg[p], (float)(rs * rs));                      // :599
         const int x = xs[p];
         const size_t px = (size_t)y * f.W + x;
-        if (f.rgb) st3(f.rgb + 3 * px, avg);
+        if (f.rgb) st3(f.rgb + 3 * px, out);
         if (f.index) f.index[px] = best_i[p];
         if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)                  // :618-620
-            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(out);
     }
 }
 

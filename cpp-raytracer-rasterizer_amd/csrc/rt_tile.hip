@@ -95,6 +95,9 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
     const v3 cam = ld3(f.cam);
 
     // ---- primary candidates: one lane per triangle tests the tile's pixel rectangle ----
+    // (with supersampling the sub-rays reach half a pixel beyond the pixel centres on every side)
+    const int rs = f.aa;
+    const float reach = rs > 1 ? 0.5f : 0.0f;
     bool cand = false;
     if (lane < n) {
         TriBinFns t;
@@ -105,81 +108,94 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
         t.s.c0 = d4.x; t.s.cu = d4.y; t.s.cv = d4.z; t.s.m = d4.w;
         t.nb = s_cam[3 * lane].w;
         t.bstate = BOX_NONE; t.bu0 = t.bu1 = t.bv0 = t.bv1 = 0.0f;
-        cand = rect_may_hit(t, (float)x0, (float)min(x0 + TW - 1, f.W - 1), (float)y0, (float)min(y0 + TH - 1, f.y1 - 1));
+        cand = rect_may_hit(t, (float)x0 - reach, (float)min(x0 + TW - 1, f.W - 1) + reach,
+                            (float)y0 - reach, (float)min(y0 + TH - 1, f.y1 - 1) + reach);
     }
-    unsigned long long pm = __ballot(cand);
-    unsigned ntests = ok ? (unsigned)__popcll(pm) : 0u;      // ray-triangle tests this lane runs (roofline bookkeeping)
+    const unsigned long long pmask = __ballot(cand);
+    unsigned ntests = 0;                                                     // ray-triangle tests this lane runs
 
-    // d = (x - W/2, y - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
-    const v3 d = V3((float)x - (float)f.W / 2.0f, (float)y - (float)f.H / 2.0f, f.focal);
-    const v3 nd = neg3(mat3_mul_vec(f.rot, d));
-    float best_d = FLT_MAX;                                                  // Update() reset (:335-339)
+    float best_d = FLT_MAX;                                                  // Update() reset (:335-339), once per frame
     int best_i = -1;
     v3 pos = V3(0.0f, 0.0f, 0.0f);
-    while (pm) {                                                             // ascending index: the `>=` rule holds
-        const int j = __builtin_ctzll(pm);
-        pm &= pm - 1ull;
-        const float4 r0 = s_cam[3 * j], r1 = s_cam[3 * j + 1], r2 = s_cam[3 * j + 2];
-        const TestDots td = test_dots(r0, r1, r2, nd);
-        if (maybe_hit(td)) {
-            v3 hp;
-            float dist;
-            if (exact_hit_geo(td, r0.w, s_geo + 3 * j, cam, &hp, &dist))
-                if (best_d >= dist) { best_d = dist; best_i = j; pos = hp; }     // :243-247
-        }
-    }
-
-    const bool hit = ok && best_i >= 0;
-    count_hits(f, (unsigned long long)__popcll(__ballot(hit)));
-
     v3 avg = V3(0.0f, 0.0f, 0.0f);
-    if (__any(hit)) {
-        const int bi = best_i >= 0 ? best_i : 0;
-        const float4 sh0 = s_shade[2 * bi], sh1 = s_shade[2 * bi + 1];
-        const v3 nDir = V3(sh0.x, sh0.y, sh0.z);                             // glm::normalize(normal) (:300), per triangle
-        const v3 tcol = V3(sh1.x, sh1.y, sh1.z);
-        v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
-        for (int k = 0; k < f.nlights; k++) {
-            const v3 L = ld3(f.lpos[k]);
-            v3 rd;
-            float r;
-            v3 D = light_term(f, k, pos, nDir, &rd, &r);
-            const float thr = r * 0.99f;                                     // :313
-            const float4 *tab = s_light + (size_t)3 * n * k;
-            // ---- shadow candidates: direction box of the wave's live rays, one lane per triangle ----
-            const float inf = __builtin_huge_valf();
-            const v3 lo = V3(wave_min_f(hit ? rd.x : inf), wave_min_f(hit ? rd.y : inf), wave_min_f(hit ? rd.z : inf));
-            const v3 hi = V3(wave_max_f(hit ? rd.x : -inf), wave_max_f(hit ? rd.y : -inf), wave_max_f(hit ? rd.z : -inf));
-            bool sc = false;
-            if (lane < n) sc = box_may_hit(tab[3 * lane], tab[3 * lane + 1], tab[3 * lane + 2], lo, hi);
-            unsigned long long sm = __ballot(sc);
-            if (hit) ntests += (unsigned)__popcll(sm);
-            bool live = hit;
-            while (sm) {
-                const int j = __builtin_ctzll(sm);
-                sm &= sm - 1ull;
-                const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
-                const TestDots td = test_dots(r0, r1, r2, rd);               // negD = rDir (:310, :229)
-                if (live && maybe_hit(td)) {
+    float y1 = aa_start(y, rs);                                              // :566-569
+    for (int z = 0; z < rs; z++) {
+        float x1 = aa_start(x, rs);                                          // :573-576
+        for (int z2 = 0; z2 < rs; z2++) {
+            // d = (x1 - W/2, y1 - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
+            const v3 d = V3(x1 - (float)f.W / 2.0f, y1 - (float)f.H / 2.0f, f.focal);
+            const v3 nd = neg3(mat3_mul_vec(f.rot, d));
+            bool any = false;                                                // ClosestIntersection's return value
+            unsigned long long pm = pmask;
+            if (ok) ntests += (unsigned)__popcll(pm);
+            while (pm) {                                                     // ascending index: the `>=` rule holds
+                const int j = __builtin_ctzll(pm);
+                pm &= pm - 1ull;
+                const float4 r0 = s_cam[3 * j], r1 = s_cam[3 * j + 1], r2 = s_cam[3 * j + 2];
+                const TestDots td = test_dots(r0, r1, r2, nd);
+                if (maybe_hit(td)) {
                     v3 hp;
                     float dist;
-                    if (exact_hit_geo(td, r0.w, s_geo + 3 * j, L, &hp, &dist) && dist < thr) {
-                        live = false;                                         // occluded (:313-314); any-hit is exact
-                        D = V3(0.0f, 0.0f, 0.0f);
+                    if (exact_hit_geo(td, r0.w, s_geo + 3 * j, cam, &hp, &dist)) {
+                        any = true;
+                        if (best_d >= dist) { best_d = dist; best_i = j; pos = hp; }     // :243-247 (carried across sub-rays)
                     }
                 }
             }
-            result = add3(result, D);                                        // :319
-            if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // :322, after each light's samples
+            const bool hit = ok && any;
+            count_hits(f, (unsigned long long)__popcll(__ballot(hit)));
+
+            if (__any(hit)) {
+                const int bi = best_i >= 0 ? best_i : 0;
+                const float4 sh0 = s_shade[2 * bi], sh1 = s_shade[2 * bi + 1];
+                const v3 nDir = V3(sh0.x, sh0.y, sh0.z);                     // glm::normalize(normal) (:300), per triangle
+                const v3 tcol = V3(sh1.x, sh1.y, sh1.z);
+                v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
+                for (int k = 0; k < f.nlights; k++) {
+                    const v3 L = ld3(f.lpos[k]);
+                    v3 rd;
+                    float r;
+                    v3 D = light_term(f, k, pos, nDir, &rd, &r);
+                    const float thr = r * 0.99f;                             // :313
+                    const float4 *tab = s_light + (size_t)3 * n * k;
+                    // ---- shadow candidates: direction box of the wave's live rays, one lane per triangle ----
+                    const float inf = __builtin_huge_valf();
+                    const v3 lo = V3(wave_min_f(hit ? rd.x : inf), wave_min_f(hit ? rd.y : inf), wave_min_f(hit ? rd.z : inf));
+                    const v3 hi = V3(wave_max_f(hit ? rd.x : -inf), wave_max_f(hit ? rd.y : -inf), wave_max_f(hit ? rd.z : -inf));
+                    bool sc = false;
+                    if (lane < n) sc = box_may_hit(tab[3 * lane], tab[3 * lane + 1], tab[3 * lane + 2], lo, hi);
+                    unsigned long long sm = __ballot(sc);
+                    if (hit) ntests += (unsigned)__popcll(sm);
+                    bool live = hit;
+                    while (sm) {
+                        const int j = __builtin_ctzll(sm);
+                        sm &= sm - 1ull;
+                        const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
+                        const TestDots td = test_dots(r0, r1, r2, rd);       // negD = rDir (:310, :229)
+                        if (live && maybe_hit(td)) {
+                            v3 hp;
+                            float dist;
+                            if (exact_hit_geo(td, r0.w, s_geo + 3 * j, L, &hp, &dist) && dist < thr) {
+                                live = false;                                 // occluded (:313-314); any-hit is exact
+                                D = V3(0.0f, 0.0f, 0.0f);
+                            }
+                        }
+                    }
+                    result = add3(result, D);                                // :319
+                    if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // :322, after each light's samples
+                }
+                if (hit) {
+                    const v3 Dl = mul3(result2, tcol);                       // :325-326
+                    avg = add3(avg, mul3(tcol, add3(Dl, ld3(f.indirect))));  // :584-591
+                    x1 += aa_step(rs);                                       // :593, only after a hit
+                }
+            }
         }
-        if (hit) {
-            const v3 Dl = mul3(result2, tcol);                               // :325-326
-            avg = add3(avg, mul3(tcol, add3(Dl, ld3(f.indirect))));          // :584-591
-        }
+        y1 += aa_step(rs);                                                   // :596
     }
     count_tests(f, ntests);
     if (!ok) return;
-    avg = div3s(avg, 1.0f);                                                  // :599
+    avg = div3s(avg, (float)(rs * rs));                                      // :599
     const size_t px = (size_t)y * f.W + x;
     if (f.rgb) st3(f.rgb + 3 * px, avg);
     if (f.index) f.index[px] = best_i;

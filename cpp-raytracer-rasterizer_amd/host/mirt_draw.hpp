@@ -86,6 +86,8 @@ struct RayTracer {
     Surface screen = { nullptr, 0, 0, 0 };           // :76
     bool isUpdated = true;                           // :78
     bool scene_dirty = true;                         // set when `triangles` changes
+    bool AA_ENABLED = false;                         // :37
+    int AA_SAMPLES = 3;                              // :38
     bool SOFT_SHADOWS_ENABLED = false;               // :40
     int SOFT_SHADOWS_SAMPLES = 16;                   // :41
     vec3 randomPositions[256];                       // :84
@@ -120,6 +122,7 @@ struct RayTracer {
             scene_dirty = false;
         }
         const mirt_view view = make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
+        check(mirt_set_antialiasing(AA_ENABLED ? AA_SAMPLES : 1), "mirt_set_antialiasing");   // realSamples (:549-554)
         if (SOFT_SHADOWS_ENABLED)                                  // DirectLight's `samples` (:272-275)
             check(mirt_set_soft_shadows(SOFT_SHADOWS_SAMPLES, &randomPositions[0].x, NUM_LIGHTS * SOFT_SHADOWS_SAMPLES), "mirt_set_soft_shadows");
         else

@@ -20,7 +20,7 @@ KERNEL_NAMES = ("prep", "bin", "trace", "shade", "raster_setup", "raster_frag", 
 EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
-    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
+    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats",
 )
 
@@ -176,6 +176,11 @@ def scene_upload(tris, culled=None):
 def scene_set_culled(culled):
     culled = np.ascontiguousarray(culled, np.uint8)
     _check(load().mirt_scene_set_culled(_ptr(culled), len(culled)))
+
+
+def set_antialiasing(samples):
+    """samples x samples sub-rays per pixel (the reference's AA_SAMPLES = 3); <= 1 switches it off."""
+    _check(load().mirt_set_antialiasing(int(samples)))
 
 
 def set_soft_shadows(samples, positions=None):

@@ -129,6 +129,11 @@ MIRT_API int mirt_cull(const float *tris15, int n, const mirt_view *view, int fl
  * hard shadows.  lights x samples may not exceed MIRT_MAX_LIGHTS. */
 MIRT_API int mirt_set_soft_shadows(int samples, const float *positions, int npositions);
 
+/* Supersampling (AA_ENABLED / AA_SAMPLES, raytracer.cpp:37-38,549-599): samples > 1 fires samples x samples sub-rays
+ * per pixel and averages them, reproducing the reference's loop exactly (the pixel's closest-hit record is carried
+ * across the sub-rays, x1 only advances after a sub-ray that hit).  samples <= 1 switches it off.  The reference uses 3. */
+MIRT_API int mirt_set_antialiasing(int samples);
+
 /* ---- ray tracer: replaces Draw() + CalculateDOF() of raytracer.cpp:547-656 -------------------------- */
 
 /* One frame into host buffers.  out_xrgb (required) is the SDL surface's `pixels` (XRGB8888, the words

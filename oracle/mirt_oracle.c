@@ -337,12 +337,12 @@ static inline uint32_t pack_xrgb(v3 c) { return (chan8(c.x) << 16) | (chan8(c.y)
  * written (:618-620), the border keeps its previous value.  Any output may be NULL.
  * Returns the number of shadow rays traced (nlights per pixel whose primary ray hit).
  */
-ORACLE_API uint64_t mirt_oracle_raytrace_soft(const float *tris15, int n, const float *cam_pos, const float *rot9,
-                                              float focal, int W, int H, const float *lights7, int nlights,
-                                              int samples, const float *jitter,
-                                              const float *indirect, int y0, int y1, int threads,
-                                              float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
-                                              uint32_t *out_xrgb, int pitch_words);
+ORACLE_API uint64_t mirt_oracle_raytrace_ex(const float *tris15, int n, const float *cam_pos, const float *rot9,
+                                            float focal, int W, int H, const float *lights7, int nlights,
+                                            int samples, const float *jitter, int aa,
+                                            const float *indirect, int y0, int y1, int threads,
+                                            float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
+                                            uint32_t *out_xrgb, int pitch_words);
 
 ORACLE_API uint64_t mirt_oracle_raytrace(const float *tris15, int n, const float *cam_pos, const float *rot9,
                                          float focal, int W, int H, const float *lights7, int nlights,
@@ -350,12 +350,10 @@ ORACLE_API uint64_t mirt_oracle_raytrace(const float *tris15, int n, const float
                                          float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
                                          uint32_t *out_xrgb, int pitch_words)
 {
-    return mirt_oracle_raytrace_soft(tris15, n, cam_pos, rot9, focal, W, H, lights7, nlights, 1, NULL, indirect, y0, y1,
-                                     threads, out_rgb, out_index, out_dist, out_pos, out_xrgb, pitch_words);
+    return mirt_oracle_raytrace_ex(tris15, n, cam_pos, rot9, focal, W, H, lights7, nlights, 1, NULL, 1, indirect, y0, y1,
+                                   threads, out_rgb, out_index, out_dist, out_pos, out_xrgb, pitch_words);
 }
 
-/* The same with soft shadows: `samples` jittered positions per light (jitter[(k*samples+i)*3], what AddLight stores in
- * randomPositions, raytracer.cpp:186-190); samples == 1 is the hard-shadow path.  Returns the shadow rays traced. */
 ORACLE_API uint64_t mirt_oracle_raytrace_soft(const float *tris15, int n, const float *cam_pos, const float *rot9,
                                               float focal, int W, int H, const float *lights7, int nlights,
                                               int samples, const float *jitter,
@@ -363,9 +361,25 @@ ORACLE_API uint64_t mirt_oracle_raytrace_soft(const float *tris15, int n, const 
                                               float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
                                               uint32_t *out_xrgb, int pitch_words)
 {
+    return mirt_oracle_raytrace_ex(tris15, n, cam_pos, rot9, focal, W, H, lights7, nlights, samples, jitter, 1, indirect,
+                                   y0, y1, threads, out_rgb, out_index, out_dist, out_pos, out_xrgb, pitch_words);
+}
+
+/* The general form.  samples > 1: soft shadows with `samples` jittered positions per light (jitter[(k*samples+i)*3],
+ * what AddLight stores in randomPositions, raytracer.cpp:186-190).  aa > 1: supersampling with realSamples = aa
+ * (AA_ENABLED / AA_SAMPLES, :37-38, 549-599) including the reference's quirks: closestIntersections[pixel] is NOT reset
+ * between the aa*aa sub-rays, so a later sub-ray shades the nearest hit found so far (possibly an earlier sub-ray's), and
+ * x1 only advances after a sub-ray that hit something.  Returns the shadow rays traced. */
+ORACLE_API uint64_t mirt_oracle_raytrace_ex(const float *tris15, int n, const float *cam_pos, const float *rot9,
+                                            float focal, int W, int H, const float *lights7, int nlights,
+                                            int samples, const float *jitter, int aa,
+                                            const float *indirect, int y0, int y1, int threads,
+                                            float *out_rgb, int32_t *out_index, float *out_dist, float *out_pos,
+                                            uint32_t *out_xrgb, int pitch_words)
+{
     uint64_t nshadow = 0;
     const v3 camera = ld3(cam_pos), N = ld3(indirect);
-    const float halfW = (float)W / 2.0f, halfH = (float)H / 2.0f;
+    const float halfW = (float)W / 2.0f, halfH = (float)H / 2.0f;          /* (float)SCREEN_WIDTH/2.0f */
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #else
@@ -375,19 +389,29 @@ ORACLE_API uint64_t mirt_oracle_raytrace_soft(const float *tris15, int n, const 
     for (int y = y0; y < y1; y++) {
         for (int x = 0; x < W; x++) {
             size_t px = (size_t)y * W + x;
-            v3 d = V((float)x - halfW, (float)y - halfH, focal);                /* :579 */
             hit_t c;
-            c.distance = FLT_MAX; c.index = -1; c.position = V(0, 0, 0);        /* Update() :335-339 */
+            c.distance = FLT_MAX; c.index = -1; c.position = V(0, 0, 0);        /* Update() :335-339, once per frame */
             v3 avg = V(0, 0, 0);
-            if (closest_intersection(camera, mat3_mul_vec(rot9, d), tris15, n, &c)) {   /* :580 */
-                v3 D = direct_light(&c, tris15, n, lights7, nlights, samples, jitter);   /* :583 */
-                v3 T = add3(D, N);                                              /* :584-586 */
-                v3 p = ld3(tris15 + (size_t)15 * c.index + 12);                 /* :587 */
-                v3 R = mul3(p, T);                                              /* :588 */
-                avg = add3(avg, R);                                             /* :591 */
-                nshadow += (uint64_t)nlights * (uint64_t)samples;
+            const int realSamples = aa > 1 ? aa : 1;                            /* :549-554 */
+            float x1, y1;
+            if (realSamples > 1) y1 = y - 0.5f; else y1 = y;                    /* :566-569 */
+            for (int z = 0; z < realSamples; z++) {
+                if (realSamples > 1) x1 = x - 0.5f; else x1 = x;                /* :573-576 */
+                for (int z2 = 0; z2 < realSamples; z2++) {
+                    v3 d = V(x1 - halfW, y1 - halfH, focal);                    /* :579 */
+                    if (closest_intersection(camera, mat3_mul_vec(rot9, d), tris15, n, &c)) {   /* :580 */
+                        v3 D = direct_light(&c, tris15, n, lights7, nlights, samples, jitter);   /* :583 */
+                        v3 T = add3(D, N);                                      /* :584-586 */
+                        v3 p = ld3(tris15 + (size_t)15 * c.index + 12);         /* :587 */
+                        v3 R = mul3(p, T);                                      /* :588 */
+                        avg = add3(avg, R);                                     /* :591 */
+                        x1 += (1.0f / (float)(realSamples - 1));                /* :593, only after a hit */
+                        nshadow += (uint64_t)nlights * (uint64_t)samples;
+                    }
+                }
+                y1 += (1.0f / (float)(realSamples - 1));                        /* :596 */
             }
-            avg = div3s(avg, (float)(1 * 1));                                   /* :599 */
+            avg = div3s(avg, (float)(realSamples * realSamples));               /* :599 */
             if (out_rgb) st3(out_rgb + 3 * px, avg);                            /* :600 */
             if (out_index) out_index[px] = c.index;
             if (out_dist) out_dist[px] = c.distance;

@@ -46,6 +46,9 @@ class Oracle:
         lib.mirt_oracle_raytrace_soft.restype = C.c_uint64
         lib.mirt_oracle_raytrace_soft.argtypes = [f32p, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, _vp, C.c_int,
                                                   C.c_int, _vp, f32p, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
+        lib.mirt_oracle_raytrace_ex.restype = C.c_uint64
+        lib.mirt_oracle_raytrace_ex.argtypes = [f32p, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, _vp, C.c_int,
+                                                C.c_int, _vp, C.c_int, f32p, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
         lib.mirt_oracle_jitter.argtypes = [f32p, C.c_int, f32p]
         lib.mirt_oracle_cull.argtypes = [f32p, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, C.c_int, _vp]
         lib.mirt_oracle_vertex_shader.argtypes = [f32p, f32p, f32p, C.c_float, C.c_int, C.c_int,
@@ -89,9 +92,9 @@ class Oracle:
         return out
 
     def raytrace(self, tris, cam_pos, rot9, focal, W, H, lights, indirect=(0.2, 0.2, 0.2), y0=0, y1=None,
-                 threads=0, want=("rgb", "index", "dist", "pos", "xrgb"), samples=1, jitter=None):
+                 threads=0, want=("rgb", "index", "dist", "pos", "xrgb"), samples=1, jitter=None, aa=1):
         """Returns dict(rgb, index, dist, pos, xrgb, nshadow); full-frame planes, band rows filled.
-        samples > 1: soft shadows with `jitter` = (nlights*samples, 3) positions."""
+        samples > 1: soft shadows with `jitter` = (nlights*samples, 3) positions; aa > 1: aa x aa supersampling."""
         tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 15)
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 7)
         y1 = H if y1 is None else y1
@@ -103,9 +106,9 @@ class Oracle:
             "xrgb": np.zeros((H, W), np.uint32) if "xrgb" in want else None,
         }
         jit = None if jitter is None else np.ascontiguousarray(jitter, np.float32)
-        ns = self.lib.mirt_oracle_raytrace_soft(
+        ns = self.lib.mirt_oracle_raytrace_ex(
             tris, len(tris), np.asarray(cam_pos, np.float32), np.ascontiguousarray(rot9, np.float32), float(focal),
-            W, H, _ptr(lights) if len(lights) else None, len(lights), int(samples), _ptr(jit),
+            W, H, _ptr(lights) if len(lights) else None, len(lights), int(samples), _ptr(jit), int(aa),
             np.asarray(indirect, np.float32), y0, y1,
             threads, _ptr(out["rgb"]), _ptr(out["index"]), _ptr(out["dist"]), _ptr(out["pos"]), _ptr(out["xrgb"]), W)
         out["nshadow"] = int(ns)

@@ -21,19 +21,21 @@ def device():
     mirt.shutdown()
 
 
-def _rt_compare(oracle, tris, cam, rot, focal, W, H, lights, mode=mirt.RT_BRUTE, threads=16, samples=1, jitter=None):
-    ref = oracle.raytrace(tris, cam, rot, focal, W, H, lights, threads=threads, samples=samples, jitter=jitter)
+def _rt_compare(oracle, tris, cam, rot, focal, W, H, lights, mode=mirt.RT_BRUTE, threads=16, samples=1, jitter=None, aa=1):
+    ref = oracle.raytrace(tris, cam, rot, focal, W, H, lights, threads=threads, samples=samples, jitter=jitter, aa=aa)
     mirt.scene_upload(tris)
     mirt.set_soft_shadows(samples, jitter)
+    mirt.set_antialiasing(aa)
     try:
         got = mirt.raytrace(mirt.make_view(cam, rot, focal, W, H), lights, mode=mode)
     finally:
         mirt.set_soft_shadows(1)
+        mirt.set_antialiasing(1)
     assert np.array_equal(got["index"], ref["index"]), "closest-hit index differs in %d pixels" % int((got["index"] != ref["index"]).sum())
     assert np.max(np.abs(got["rgb"] - ref["rgb"])) <= TOL
     assert np.array_equal(got["rgb"].view(np.uint32), ref["rgb"].view(np.uint32)), "float colours not bit-identical"
     assert np.array_equal(got["xrgb"], ref["xrgb"])
-    assert got["stats"]["primary_rays"] == W * H
+    assert got["stats"]["primary_rays"] == W * H * aa * aa
     assert got["stats"]["shadow_rays"] == ref["nshadow"]
     return got, ref
 
@@ -157,6 +159,32 @@ def test_rt_soft_shadows_two_lights(oracle, mode, n):
     jit = _jitter(oracle, lights, 4)
     tris = mirt.scene_soup(17, n, 0.25 if n < 100 else 0.1)
     _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(-0.2, 1.0), 110.0, 240, 200, lights, mode=mode, samples=4, jitter=jit)
+
+
+# ---- supersampling (parity unpinned: no recorded reference output) ----------------
+
+def test_rt_supersampling_cornell(oracle):
+    """AA_SAMPLES = 3: nine sub-rays per pixel with the reference's carried closest-hit record and hit-only x1 advance
+    (raytracer.cpp:549-599).  Cornell box: the tile-mask kernel, rectangles widened by the sub-pixel reach."""
+    got, ref = _rt_compare(oracle, mirt.scene_cornell(), (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 100.0, 200, 200,
+                           DEFAULT_LIGHT, mode=mirt.RT_AUTO, aa=3)
+    plain = oracle.raytrace(mirt.scene_cornell(), (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 100.0, 200, 200, DEFAULT_LIGHT)
+    assert not np.array_equal(ref["rgb"], plain["rgb"])                  # it does change the image
+
+
+@pytest.mark.parametrize("mode,n,aa", [(mirt.RT_BRUTE, 90, 3), (mirt.RT_BRUTE, 1500, 2), (mirt.RT_BINNED, 2500, 3), (mirt.RT_AUTO, 30, 4)])
+def test_rt_supersampling_all_kernels(oracle, mode, n, aa):
+    """Sparse soups leave many sub-rays without a hit, which exercises the `x1 advances only after a hit` quirk and
+    the carried record (a sub-ray that hits something farther still shades the nearest hit found so far)."""
+    tris = mirt.scene_soup(55 + n, n, 0.25 if n < 100 else 0.08)
+    lights = np.array([[0, -0.5, -0.7, 1, 1, 1, 14], [0.4, 0.3, -0.9, 0.6, 0.9, 0.3, 7]], np.float32)
+    _rt_compare(oracle, tris, (0, 0, -2), oracle.rot_from_yaw(0.15, 1.0), 70.0, 150, 110, lights, mode=mode, aa=aa)
+
+
+def test_rt_supersampling_with_soft_shadows(oracle):
+    jit = _jitter(oracle, DEFAULT_LIGHT, 4)
+    _rt_compare(oracle, mirt.scene_cornell(), (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 60.0, 120, 120, DEFAULT_LIGHT,
+                mode=mirt.RT_AUTO, samples=4, jitter=jit, aa=3)
 
 
 def test_rt_soft_shadows_limits():
@@ -306,7 +334,7 @@ def test_errors_are_reported_not_fatal():
 
 # ---- the C++ host adapter (reference-shaped Draw()) ---------------------------------------------------
 
-@pytest.mark.parametrize("which", ["rt", "rtsoft", "raster"])
+@pytest.mark.parametrize("which", ["rt", "rtsoft", "rtaa", "raster"])
 def test_host_draw_adapter_matches_oracle(oracle, tmp_path, which):
     """cpp-raytracer-rasterizer_amd/host/demo_main runs the reference's main loop shape (Update(); Draw();) through
     mirt_draw.hpp and the C-ABI; its surface must hold exactly the words the oracle's PutPixelSDL path produces."""
@@ -326,6 +354,8 @@ def test_host_draw_adapter_matches_oracle(oracle, tmp_path, which):
     tris = oracle.cornell()
     if which == "rt":
         ref = oracle.raytrace(tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), H / 2.0, W, H, DEFAULT_LIGHT)["xrgb"]
+    elif which == "rtaa":
+        ref = oracle.raytrace(tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), H / 2.0, W, H, DEFAULT_LIGHT, aa=3)["xrgb"]
     elif which == "rtsoft":
         # the adapter draws its jitter from rand() exactly as AddLight does (first 48 values of the default stream)
         jit = _jitter(oracle, DEFAULT_LIGHT, 16)
