@@ -27,7 +27,7 @@ struct RtTileFrame {
     int tiles_per_wave;
     unsigned long long *clear_hits;
 };
-template <int TW> __global__ void k_rt_tile(const RtTileFrame);
+template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
@@ -37,7 +37,7 @@ struct RtBinnedFrame {
     int tiles_x;
     int cube_bins;
 };
-__global__ void k_rt_binned(const RtBinnedFrame);
+template <bool AA> __global__ void k_rt_binned(const RtBinnedFrame);
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
 
 namespace {
@@ -349,9 +349,10 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         tf.clear_hits = g.d_hits2[g.hits_cur ^ 1];       // zeroed by this launch for the next frame: no memset node per frame
         g.hits_clean[g.hits_cur ^ 1] = true;
         k_begin(MIRT_K_TRACE);
-        if (tile_w == 8) hipLaunchKernelGGL(k_rt_tile<8>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
-        else if (tile_w == 16) hipLaunchKernelGGL(k_rt_tile<16>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
-        else hipLaunchKernelGGL(k_rt_tile<64>, dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        if (f.aa > 1) hipLaunchKernelGGL((k_rt_tile<16, true>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        else if (tile_w == 8) hipLaunchKernelGGL((k_rt_tile<8, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        else if (tile_w == 16) hipLaunchKernelGGL((k_rt_tile<16, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        else hipLaunchKernelGGL((k_rt_tile<64, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
         k_end(MIRT_K_TRACE);
         HIP_TRY(hipGetLastError());
         call_end();
@@ -522,7 +523,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     bf.cube_bins = cube_bins;
     const int tile_rows = frames[0].j1 - frames[0].j0;
     k_begin(MIRT_K_TRACE);
-    hipLaunchKernelGGL(k_rt_binned, dim3((bf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), 0, g.stream, bf);
+    if (f.aa > 1) hipLaunchKernelGGL(k_rt_binned<true>, dim3((bf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), 0, g.stream, bf);
+    else hipLaunchKernelGGL(k_rt_binned<false>, dim3((bf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), 0, g.stream, bf);
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();

@@ -178,6 +178,7 @@ __device__ __forceinline__ bool closer(float dist, int idx, float best_d, int be
     return dist < best_d || (dist == best_d && idx > best_i);
 }
 
+template <bool AA>
 __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
 {
     const RtFrame &f = bf.f;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
     const bool ok = tile_ok && x < f.W && y >= f.y0 && y < f.y1;
     if (!tile_ok) return;                                  // wave-uniform
     const v3 cam = ld3(f.cam);
-    const int rs = f.aa;                                   // realSamples (:549-554)
+    const int rs = AA ? f.aa : 1;                          // realSamples (:549-554); compile-time 1 without supersampling
 
     const uint32_t cbin = bf.cam_base + (uint32_t)ty * bf.tiles_x + tx;
     const uint32_t cbeg = bf.bins.bin_off[cbin], cend = bf.bins.bin_off[cbin + 1];
@@ -228,11 +229,9 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float4 n0 = s_rows[wave][0], n1 = s_rows[wave][1], n2 = s_rows[wave][2];
+#pragma unroll 2
                 for (int j = 0; j < cnt; j++) {
-                    const float4 r0 = n0, r1 = n1, r2 = n2;   // software pipeline: row j+1 loads while row j is tested
-                    const int jn = min(j + 1, cnt - 1);
-                    n0 = s_rows[wave][3 * jn]; n1 = s_rows[wave][3 * jn + 1]; n2 = s_rows[wave][3 * jn + 2];
+                    const float4 r0 = s_rows[wave][3 * j], r1 = s_rows[wave][3 * j + 1], r2 = s_rows[wave][3 * j + 2];
                     const TestDots td = test_dots(r0, r1, r2, nd);
                     if (maybe_hit(td)) {
                         const int idx = (int)s_idx[wave][j];
@@ -304,5 +303,8 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
     if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)            // (:618-620)
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
+
+template __global__ void k_rt_binned<false>(const RtBinnedFrame);
+template __global__ void k_rt_binned<true>(const RtBinnedFrame);
 
 }  // namespace mirt

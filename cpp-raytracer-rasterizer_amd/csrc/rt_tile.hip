@@ -82,7 +82,7 @@ __device__ __forceinline__ bool exact_hit_geo(const TestDots &d, float e1e2b, co
     return false;
 }
 
-template <int TW>
+template <int TW, bool AA>
 __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty, const float4 *s_cam, const float4 *s_geo,
                                           const float4 *s_fns, const float4 *s_shade, const float4 *s_light)
 {
@@ -96,7 +96,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
 
     // ---- primary candidates: one lane per triangle tests the tile's pixel rectangle ----
     // (with supersampling the sub-rays reach half a pixel beyond the pixel centres on every side)
-    const int rs = f.aa;
+    const int rs = AA ? f.aa : 1;                 // compile-time 1 without supersampling: the loops below fold away
     const float reach = rs > 1 ? 0.5f : 0.0f;
     bool cand = false;
     if (lane < n) {
@@ -203,7 +203,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
 
-template <int TW>
+template <int TW, bool AA>
 __global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
@@ -248,12 +248,13 @@ __global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
     for (int i = 0; i < tf.tiles_per_wave; i++) {
         const long long tile = first + i;
         if (tile >= ntiles) break;
-        tile_body<TW>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), s_cam, s_geo, s_fns, s_shade, s_light);
+        tile_body<TW, AA>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), s_cam, s_geo, s_fns, s_shade, s_light);
     }
 }
 
-template __global__ void k_rt_tile<8>(const RtTileFrame);
-template __global__ void k_rt_tile<16>(const RtTileFrame);
-template __global__ void k_rt_tile<64>(const RtTileFrame);
+template __global__ void k_rt_tile<8, false>(const RtTileFrame);
+template __global__ void k_rt_tile<16, false>(const RtTileFrame);
+template __global__ void k_rt_tile<64, false>(const RtTileFrame);
+template __global__ void k_rt_tile<16, true>(const RtTileFrame);
 
 }  // namespace mirt
