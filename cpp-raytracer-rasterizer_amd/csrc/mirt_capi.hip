@@ -28,6 +28,18 @@ struct RtTileFrame {
     unsigned long long *clear_hits;
 };
 template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
+struct DofFrame {
+    const float *rgb;
+    const float *fd;
+    int W, H;
+    int K;
+    int y0, y1, row_origin;
+    int ry0, ry1;
+    uint32_t *xrgb;
+    int pitch_words;
+    int clear_border;
+};
+__global__ void k_dof(const DofFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
@@ -87,6 +99,13 @@ struct Ctx {
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
     int soft_samples = 1;                        // soft-shadow samples per light (1 = hard shadows)
     int aa = 1;                                  // realSamples of Draw(): AA_SAMPLES when AA_ENABLED, else 1
+    int dof_k = 0;                               // DOF_KERNEL_SIZE when DOF_ENABLED, else 0
+    float dof_focal = 0.0f;                      // FOCAL_LENGTH
+    float *d_dof_rgb = nullptr, *d_dof_fd = nullptr;     // pixelColours / focalDistances of the band + halo
+    uint32_t *d_dof_xrgb = nullptr;              // unblurred words the render kernels emit (discarded)
+    int32_t *d_dof_index = nullptr;
+    float *d_dof_zinv = nullptr;
+    size_t dof_cap_px = 0;
     int soft_npos = 0;
     float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
 
@@ -236,7 +255,7 @@ BinFrameDesc make_camera_frame(const mirt_view *view, int y0, int y1, int aa)
 }
 
 int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect, int mode,
-               int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index)
+               int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index, void *d_fd = nullptr)
 {
     int rc;
     if ((rc = need_init())) return rc;
@@ -302,6 +321,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     f.pitch_words = pitch_bytes / 4;
     f.rgb = static_cast<float *>(d_rgb);
     f.index = static_cast<int32_t *>(d_index);
+    f.fd = static_cast<float *>(d_fd);
+    f.focal_plane = g.dof_focal;
     // hit counters: two buffers used alternately so that a kernel can clear the one the NEXT frame will use
     g.hits_cur ^= 1;
     g.d_hits = g.d_hits2[g.hits_cur];
@@ -541,6 +562,55 @@ int copy_plane_interior(void *dst, int dst_pitch, const void *src, int src_pitch
     return MIRT_OK;
 }
 
+// Depth of field (CalculateDOF with DOF_ENABLED, raytracer.cpp:613-640 / rasteriser.cpp:494-513): the render kernels
+// write pixelColours + focalDistances for the band AND the rows its blur taps reach into library-owned planes, then
+// k_dof resolves the band into the caller's surface.  `render(ry0, ry1, xrgb, rgb, fd, index, zinv)` runs the path.
+template <class Render>
+int render_with_dof(const mirt_view *view, int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes,
+                    void *user_rgb, void *user_index, void *user_zinv, bool clear_border, Render render)
+{
+    int rc;
+    const int W = view->width, H = view->height, K = g.dof_k;
+    const int zlo = (int)std::ceil((float)K / -2.0f), zhi = (int)std::ceil((float)K / 2.0f);
+    const int reach = std::max(-zlo, zhi - 1) + 1;           // +1: a tap column outside the row wraps into the next row
+    const int ry0 = std::max(0, y0 - reach), ry1 = std::min(H, y1 + reach);
+    const size_t npx = (size_t)W * (size_t)(ry1 - ry0);
+    if (npx > g.dof_cap_px) {
+        for (void **p : { (void **)&g.d_dof_rgb, (void **)&g.d_dof_fd, (void **)&g.d_dof_xrgb, (void **)&g.d_dof_index, (void **)&g.d_dof_zinv }) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
+        }
+        g.dof_cap_px = 0;
+        if (hipMalloc((void **)&g.d_dof_rgb, npx * 12) != hipSuccess || hipMalloc((void **)&g.d_dof_fd, npx * 4) != hipSuccess ||
+            hipMalloc((void **)&g.d_dof_xrgb, npx * 4) != hipSuccess || hipMalloc((void **)&g.d_dof_index, npx * 4) != hipSuccess ||
+            hipMalloc((void **)&g.d_dof_zinv, npx * 4) != hipSuccess)
+            return fail(MIRT_ERR_OUT_OF_MEMORY, "depth-of-field planes (%zu pixels)", npx);
+        g.dof_cap_px = npx;
+    }
+    // the kernels index their planes with full-frame pixel numbers: shift the bases so that row ry0 is the first stored
+    const ptrdiff_t shift = (ptrdiff_t)ry0 * W;
+    float *rgb = g.d_dof_rgb - 3 * shift, *fd = g.d_dof_fd - shift, *zinv = g.d_dof_zinv - shift;
+    int32_t *index = g.d_dof_index - shift;
+    if ((rc = render(ry0, ry1, (void *)g.d_dof_xrgb, (void *)rgb, (void *)fd, user_index ? (void *)index : nullptr,
+                     user_zinv ? (void *)zinv : nullptr))) return rc;
+    if (y1 > y0) {
+        DofFrame d;
+        d.rgb = rgb; d.fd = fd; d.W = W; d.H = H; d.K = K;
+        d.y0 = y0; d.y1 = y1; d.row_origin = row_origin; d.ry0 = ry0; d.ry1 = ry1;
+        d.xrgb = static_cast<uint32_t *>(d_xrgb); d.pitch_words = pitch_bytes / 4; d.clear_border = clear_border ? 1 : 0;
+        if (g.profiling) { (void)hipEventRecord(g.ev[EV_K0 + 2 * MIRT_K_SHADE], g.stream); g.ev_used[MIRT_K_SHADE] = true; }
+        hipLaunchKernelGGL(k_dof, dim3((W + 255) / 256, y1 - y0), dim3(256), 0, g.stream, d);
+        if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * MIRT_K_SHADE + 1], g.stream);
+        HIP_TRY(hipGetLastError());
+        const size_t rows = (size_t)(y1 - y0), off = (size_t)(y0 - ry0) * W, uoff = (size_t)y0 * W;
+        if (user_rgb) HIP_TRY(hipMemcpyAsync((float *)user_rgb + 3 * uoff, g.d_dof_rgb + 3 * off, rows * W * 12, hipMemcpyDeviceToDevice, g.stream));
+        if (user_index) HIP_TRY(hipMemcpyAsync((int32_t *)user_index + uoff, g.d_dof_index + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
+        if (user_zinv) HIP_TRY(hipMemcpyAsync((float *)user_zinv + uoff, g.d_dof_zinv + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
+        (void)hipEventRecord(g.ev[EV_CALL1], g.stream);          // the call ends after the blur
+    }
+    return MIRT_OK;
+}
+
 }  // namespace
 }  // namespace mirt
 
@@ -590,7 +660,8 @@ extern "C" void mirt_shutdown(void)
     (void)hipStreamSynchronize(g.stream);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
                      (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
-                     (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries })
+                     (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries,
+                     (void *)g.d_dof_rgb, (void *)g.d_dof_fd, (void *)g.d_dof_xrgb, (void *)g.d_dof_index, (void *)g.d_dof_zinv })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
@@ -656,6 +727,16 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
 
 extern "C" int mirt_scene_size(void) { return g.init ? g.n : 0; }
 
+extern "C" int mirt_set_depth_of_field(int kernel_size, float focal_length)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (kernel_size > 64) return fail(MIRT_ERR_INVALID_ARGUMENT, "DOF kernel size %d exceeds 64 (the reference uses 8)", kernel_size);
+    g.dof_k = kernel_size > 1 ? kernel_size : 0;
+    g.dof_focal = focal_length;
+    return MIRT_OK;
+}
+
 extern "C" int mirt_set_antialiasing(int samples)
 {
     int rc;
@@ -685,6 +766,11 @@ extern "C" int mirt_raytrace_device(const mirt_view *view, const mirt_light *lig
                                     int mode, int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes,
                                     void *d_rgb, void *d_index)
 {
+    if (g.init && g.dof_k > 1 && view && y0 >= 0 && y1 <= view->height && y0 <= y1 && view->width > 0)
+        return render_with_dof(view, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index, nullptr, false,
+                               [&](int ry0, int ry1, void *x, void *rgb, void *fd, void *idx, void *) {
+                                   return rt_enqueue(view, lights, nlights, indirect, mode, ry0, ry1, ry0, x, view->width * 4, rgb, idx, fd);
+                               });
     return rt_enqueue(view, lights, nlights, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index);
 }
 
@@ -699,8 +785,8 @@ extern "C" int mirt_raytrace(const mirt_view *view, const mirt_light *lights, in
     const int W = view->width, H = view->height;
     const size_t px = (size_t)W * H;
     if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, false))) return rc;
-    if ((rc = rt_enqueue(view, lights, nlights, indirect, mode, 0, H, 0, g.d_xrgb, W * 4,
-                         out_rgb ? g.d_rgb : nullptr, out_index ? g.d_index : nullptr))) return rc;
+    if ((rc = mirt_raytrace_device(view, lights, nlights, indirect, mode, 0, H, 0, g.d_xrgb, W * 4,
+                                   out_rgb ? g.d_rgb : nullptr, out_index ? g.d_index : nullptr))) return rc;
     if ((rc = copy_plane_interior(out_xrgb, pitch_bytes, g.d_xrgb, W * 4, W, H))) return rc;
     if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, g.d_rgb, px * 12, hipMemcpyDeviceToHost, g.stream));
     if (out_index) HIP_TRY(hipMemcpyAsync(out_index, g.d_index, px * 4, hipMemcpyDeviceToHost, g.stream));
@@ -712,7 +798,7 @@ extern "C" int mirt_raytrace(const mirt_view *view, const mirt_light *lights, in
 
 static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
                           int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_zinv,
-                          void *d_index)
+                          void *d_index, void *d_fd = nullptr)
 {
     int rc;
     if ((rc = need_init())) return rc;
@@ -748,6 +834,8 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     f.rgb = static_cast<float *>(d_rgb);
     f.zinv = static_cast<float *>(d_zinv);
     f.index = static_cast<int32_t *>(d_index);
+    f.fd = static_cast<float *>(d_fd);
+    f.focal_plane = g.dof_focal;
     if ((rc = raster_scratch_ensure(g.raster, g.n, view->width, y1 - y0))) return fail(rc, "raster scratch allocation failed");
     if (g.profiling) for (int k = MIRT_K_RASTER_SETUP; k <= MIRT_K_CLEAR; k++) g.ev_used[k] = true;
     if ((rc = launch_raster(f, g.raster, g.scene_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr)))
@@ -760,6 +848,11 @@ extern "C" int mirt_rasterise_device(const mirt_view *view, const mirt_light *li
                                      int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb,
                                      void *d_zinv, void *d_index)
 {
+    if (g.init && g.dof_k > 1 && view && y0 >= 0 && y1 <= view->height && y0 <= y1 && view->width > 0)
+        return render_with_dof(view, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index, d_zinv, true,
+                               [&](int ry0, int ry1, void *x, void *rgb, void *fd, void *idx, void *zinv) {
+                                   return raster_enqueue(view, lights, nlights, indirect, ry0, ry1, ry0, x, view->width * 4, rgb, zinv, idx, fd);
+                               });
     return raster_enqueue(view, lights, nlights, indirect, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_zinv, d_index);
 }
 
@@ -774,8 +867,8 @@ extern "C" int mirt_rasterise(const mirt_view *view, const mirt_light *lights, i
     const int W = view->width, H = view->height;
     const size_t px = (size_t)W * H;
     if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, out_zinv != nullptr))) return rc;
-    if ((rc = raster_enqueue(view, lights, nlights, indirect, 0, H, 0, g.d_xrgb, W * 4, out_rgb ? g.d_rgb : nullptr,
-                             out_zinv ? g.d_zinv : nullptr, out_index ? g.d_index : nullptr))) return rc;
+    if ((rc = mirt_rasterise_device(view, lights, nlights, indirect, 0, H, 0, g.d_xrgb, W * 4, out_rgb ? g.d_rgb : nullptr,
+                                    out_zinv ? g.d_zinv : nullptr, out_index ? g.d_index : nullptr))) return rc;
     // the rasteriser's Update() paints the whole surface (rasteriser.cpp:190): every word is written
     HIP_TRY(hipMemcpy2DAsync(out_xrgb, pitch_bytes, g.d_xrgb, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, g.stream));
     if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, g.d_rgb, px * 12, hipMemcpyDeviceToHost, g.stream));

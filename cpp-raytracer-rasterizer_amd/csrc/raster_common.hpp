@@ -69,6 +69,8 @@ struct RasterFrame {
     float *rgb;
     float *zinv;
     int32_t *index;
+    float *fd;               // nullable: focalDistances = distance(pPos3d, cameraPos) - FOCAL_LENGTH of the owner fragment (rasteriser.cpp:563-565), 0 where nothing was drawn
+    float focal_plane;       // FOCAL_LENGTH (:31)
     RasterScratch scratch;
 };
 

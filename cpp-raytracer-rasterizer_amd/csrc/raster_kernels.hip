@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
     const unsigned long long key = f.scratch.keys[(size_t)(y - f.y0) * f.W + x];
     v3 colour = V3(0.0f, 0.0f, 0.0f);            // Update() cleared pixelColours (:189)
     float zinv = 0.0f;                           // and depthBuffer (:188)
+    float fdist = 0.0f;
     int tri = -1;
     if (key != 0ull) {
         tri = (int)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
         v3 P = div3s(p3, zinv);                                       // pPos3d /= p.zinv (:557)
         P = vec_mul_mat3(P, f.invrot);                                // * glm::inverse(cameraRot) (:559)
         P = add3(P, ld3(f.cam));                                      // += cameraPos (:560)
+        fdist = distance3(P, ld3(f.cam)) - f.focal_plane;             // focalDistances (:563-565)
         v3 result = V3(0.0f, 0.0f, 0.0f);
         for (int k = 0; k < f.nlights; k++) {
             const v3 L = ld3(f.lpos[k]);
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
     const size_t px = (size_t)y * f.W + x;
     if (f.rgb) st3(f.rgb + 3 * px, colour);
     if (f.zinv) f.zinv[px] = zinv;
+    if (f.fd) f.fd[px] = fdist;
     if (f.index) f.index[px] = tri;
     // Update() paints every pixel black (:190); CalculateDOF then draws the interior only (:491-493)
     const bool interior = x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1;

@@ -120,6 +120,8 @@ struct RtFrame {
     int pitch_words;
     float *rgb;                 // nullable, stride W
     int32_t *index;             // nullable, stride W
+    float *fd;                  // nullable, stride W: focalDistances = closest distance - FOCAL_LENGTH (raytracer.cpp:248-249), 0 on a miss
+    float focal_plane;          // FOCAL_LENGTH (:45)
     unsigned long long *hit_count;   // HIT_SHARDS counters, HIT_SHARD_STRIDE u64 apart (see count_hits)
 };
 

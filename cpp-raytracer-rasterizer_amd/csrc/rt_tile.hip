@@ -199,6 +199,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
     const size_t px = (size_t)y * f.W + x;
     if (f.rgb) st3(f.rgb + 3 * px, avg);
     if (f.index) f.index[px] = best_i;
+    if (f.fd) f.fd[px] = best_i >= 0 ? best_d - f.focal_plane : 0.0f;          // focalDistances (:248-249)
     if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)                      // :618-620
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }

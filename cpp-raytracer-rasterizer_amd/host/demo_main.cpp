@@ -1,6 +1,7 @@
 // demo_main.cpp -- the reference's main() loops (raytracer.cpp:113-178, rasteriser.cpp:101-149) on top of
 // mirt_draw.hpp, without SDL: a heap surface stands in for the window, one Update()+Draw() per "loop".
-//   demo_main rt|rtsoft|rtaa|raster [width height [out.bmp [out.xrgb]]]   (rtsoft: SOFT_SHADOWS_ENABLED, rtaa: AA_ENABLED)
+//   demo_main rt|rtsoft|rtaa|rtdof|raster|rasterdof [width height [out.bmp [out.xrgb]]]
+//   (rtsoft: SOFT_SHADOWS_ENABLED, rtaa: AA_ENABLED, *dof: DOF_ENABLED)
 // Writes a BMP screenshot (what SDL_SaveBMP(screen, "screenshot.bmp") does at :175/:147) and, optionally, the
 // raw XRGB words so tests can compare them with the oracle.
 #include "mirt_draw.hpp"
@@ -19,10 +20,11 @@ int main(int argc, char **argv)
     try {
         std::vector<uint32_t> pixels((size_t)W * H, 0u);
         Surface screen = { pixels.data(), W, H, W * 4 };            // InitializeSDL(W, H): 32-bit SWSURFACE
-        if (which == "rt" || which == "rtsoft" || which == "rtaa") {
+        if (which == "rt" || which == "rtsoft" || which == "rtaa" || which == "rtdof") {
             RayTracer app;
             app.SOFT_SHADOWS_ENABLED = which == "rtsoft";
             app.AA_ENABLED = which == "rtaa";
+            app.DOF_ENABLED = which == "rtdof";
             app.SCREEN_WIDTH = W; app.SCREEN_HEIGHT = H;
             app.focalLength = (float)H / 2.0f;                       // 250 for the reference's 500x500
             app.screen = screen;
@@ -37,6 +39,7 @@ int main(int argc, char **argv)
             }
         } else {
             Rasteriser app;
+            app.DOF_ENABLED = which == "rasterdof";
             app.SCREEN_WIDTH = W; app.SCREEN_HEIGHT = H;
             app.focalLength = (float)H;                              // 500 for the reference's 500x500
             app.screen = screen;

@@ -90,6 +90,9 @@ struct RayTracer {
     int AA_SAMPLES = 3;                              // :38
     bool SOFT_SHADOWS_ENABLED = false;               // :40
     int SOFT_SHADOWS_SAMPLES = 16;                   // :41
+    bool DOF_ENABLED = false;                        // :43
+    int DOF_KERNEL_SIZE = 8;                         // :44
+    float FOCAL_LENGTH = 1.3f;                       // :45
     vec3 randomPositions[256];                       // :84
 
     static float RandomNumber() { return (float)(((double)std::rand() / (RAND_MAX)) - 0.5f); }   // :260-263
@@ -127,6 +130,7 @@ struct RayTracer {
             check(mirt_set_soft_shadows(SOFT_SHADOWS_SAMPLES, &randomPositions[0].x, NUM_LIGHTS * SOFT_SHADOWS_SAMPLES), "mirt_set_soft_shadows");
         else
             check(mirt_set_soft_shadows(1, nullptr, 0), "mirt_set_soft_shadows");
+        check(mirt_set_depth_of_field(DOF_ENABLED ? DOF_KERNEL_SIZE : 0, FOCAL_LENGTH), "mirt_set_depth_of_field");   // CalculateDOF (:608-646)
         check(mirt_raytrace(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLight.x,
                             MIRT_RT_AUTO, screen.pixels, screen.pitch, nullptr, nullptr), "mirt_raytrace");
     }
@@ -144,6 +148,9 @@ struct Rasteriser {
     float focalLength = 500.0f;                       // :41
     float yaw = 0.0f;
     vec3 indirectLightPowerPerArea = vec3(0.2f, 0.2f, 0.2f);   // :47
+    bool DOF_ENABLED = false;                         // :29
+    int DOF_KERNEL_SIZE = 8;                          // :30
+    float FOCAL_LENGTH = 1.9f;                        // :31
     Surface screen = { nullptr, 0, 0, 0 };
     bool isUpdated = true;
     bool scene_dirty = true;
@@ -184,6 +191,7 @@ struct Rasteriser {
             check(mirt_scene_set_culled(culled.data(), (int)culled.size()), "mirt_scene_set_culled");
         }
         const mirt_view view = make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
+        check(mirt_set_depth_of_field(DOF_ENABLED ? DOF_KERNEL_SIZE : 0, FOCAL_LENGTH), "mirt_set_depth_of_field");   // CalculateDOF (:484-529)
         check(mirt_rasterise(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLightPowerPerArea.x,
                              screen.pixels, screen.pitch, nullptr, nullptr, nullptr), "mirt_rasterise");
     }

@@ -20,7 +20,7 @@ KERNEL_NAMES = ("prep", "bin", "trace", "shade", "raster_setup", "raster_frag", 
 EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
-    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
+    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats",
 )
 
@@ -65,6 +65,7 @@ def load():
     lib.mirt_scene_soup.argtypes = [C.c_uint32, C.c_int, C.c_float, _vp]
     lib.mirt_cull.argtypes = [_vp, C.c_int, C.POINTER(View), C.c_int, _vp]
     lib.mirt_set_soft_shadows.argtypes = [C.c_int, _vp, C.c_int]
+    lib.mirt_set_depth_of_field.argtypes = [C.c_int, C.c_float]
     lib.mirt_raytrace.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
     lib.mirt_raytrace_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _vp, C.c_int, _vp, _vp]
@@ -176,6 +177,11 @@ def scene_upload(tris, culled=None):
 def scene_set_culled(culled):
     culled = np.ascontiguousarray(culled, np.uint8)
     _check(load().mirt_scene_set_culled(_ptr(culled), len(culled)))
+
+
+def set_depth_of_field(kernel_size, focal_length=0.0):
+    """kernel_size x kernel_size blur before the pixels are stored (the reference: 8, FOCAL_LENGTH 1.3 / 1.9); <= 1: off."""
+    _check(load().mirt_set_depth_of_field(int(kernel_size), float(focal_length)))
 
 
 def set_antialiasing(samples):

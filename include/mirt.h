@@ -129,6 +129,13 @@ MIRT_API int mirt_cull(const float *tris15, int n, const mirt_view *view, int fl
  * hard shadows.  lights x samples may not exceed MIRT_MAX_LIGHTS. */
 MIRT_API int mirt_set_soft_shadows(int samples, const float *positions, int npositions);
 
+/* Depth of field (DOF_ENABLED / DOF_KERNEL_SIZE / FOCAL_LENGTH, raytracer.cpp:43-45,613-640; rasteriser.cpp:29-31,
+ * 494-513): kernel_size > 1 blurs pixelColours with a kernel_size x kernel_size stencil weighted by the centre pixel's
+ * |distance - focal_length| before PutPixelSDL, for both renderers (the reference uses 8 with 1.3 / 1.9).  Taps whose
+ * flat index leaves the frame are undefined behaviour in the reference; here they contribute nothing.  out_rgb keeps
+ * the unblurred pixelColours, as in the reference.  kernel_size <= 1 switches it off. */
+MIRT_API int mirt_set_depth_of_field(int kernel_size, float focal_length);
+
 /* Supersampling (AA_ENABLED / AA_SAMPLES, raytracer.cpp:37-38,549-599): samples > 1 fires samples x samples sub-rays
  * per pixel and averages them, reproducing the reference's loop exactly (the pixel's closest-hit record is carried
  * across the sub-rays, x1 only advances after a sub-ray that hit).  samples <= 1 switches it off.  The reference uses 3. */

@@ -511,11 +511,12 @@ ORACLE_API void mirt_oracle_vertex_shader(const float *v, const float *cam_pos, 
 
 /* PixelShader, rasteriser.cpp:549-589 (inverse hoisted: same operands => same bits, E-6). */
 static v3 pixel_shader(v3 pos3d, float zinv, const float *invrot, v3 cam, const float *lights7, int nlights,
-                       v3 indirect, v3 color, v3 normal)
+                       v3 indirect, v3 color, v3 normal, float *cam_distance)
 {
     v3 P = div3s(pos3d, zinv);                                                   /* :557 */
     P = vec_mul_mat3(P, invrot);                                                 /* :559 */
     P = add3(P, cam);                                                            /* :560 */
+    *cam_distance = distance3(P, cam);                                           /* :563, feeds focalDistances :564-565 */
     v3 result = V(0, 0, 0);
     for (int i = 0; i < nlights; i++) {
         const float *l = lights7 + 7 * i;
@@ -540,11 +541,29 @@ static v3 pixel_shader(v3 pos3d, float zinv, const float *invrot, v3 cam, const 
  * (nullable) = winning triangle per pixel or -1; out_xrgb: every pixel is cleared to 0 (Update
  * paints the whole surface black, :190) then interior pixels get the resolved colour (:491-519).
  */
+ORACLE_API void mirt_oracle_rasterise_ex(const float *tris15, const uint8_t *culled, int n, const float *cam_pos,
+                                         const float *rot9, float focal, int W, int H, const float *lights7,
+                                         int nlights, const float *indirect, float focal_plane,
+                                         float *out_depth, float *out_rgb, int32_t *out_index, float *out_fd,
+                                         uint32_t *out_xrgb, int pitch_words);
+
 ORACLE_API void mirt_oracle_rasterise(const float *tris15, const uint8_t *culled, int n, const float *cam_pos,
                                       const float *rot9, float focal, int W, int H, const float *lights7,
                                       int nlights, const float *indirect,
                                       float *out_depth, float *out_rgb, int32_t *out_index,
                                       uint32_t *out_xrgb, int pitch_words)
+{
+    mirt_oracle_rasterise_ex(tris15, culled, n, cam_pos, rot9, focal, W, H, lights7, nlights, indirect, 0.0f,
+                             out_depth, out_rgb, out_index, NULL, out_xrgb, pitch_words);
+}
+
+/* The same, also returning focalDistances = distance(pPos3d, cameraPos) - FOCAL_LENGTH of the fragment that owns each
+ * pixel (rasteriser.cpp:563-565; 0 where nothing was drawn -- the reference never clears that array). */
+ORACLE_API void mirt_oracle_rasterise_ex(const float *tris15, const uint8_t *culled, int n, const float *cam_pos,
+                                         const float *rot9, float focal, int W, int H, const float *lights7,
+                                         int nlights, const float *indirect, float focal_plane,
+                                         float *out_depth, float *out_rgb, int32_t *out_index, float *out_fd,
+                                         uint32_t *out_xrgb, int pitch_words)
 {
     const v3 cam = ld3(cam_pos), ind = ld3(indirect);
     float invrot[9];
@@ -554,6 +573,7 @@ ORACLE_API void mirt_oracle_rasterise(const float *tris15, const uint8_t *culled
     for (size_t i = 0; i < npx; i++) out_depth[i] = 0.0f;                        /* :188 */
     memset(rgb, 0, npx * 3 * sizeof(float));                                     /* :189 */
     if (out_index) for (size_t i = 0; i < npx; i++) out_index[i] = -1;
+    if (out_fd) for (size_t i = 0; i < npx; i++) out_fd[i] = 0.0f;
 
     pixel_t *left = NULL, *right = NULL, *edge = NULL;
     size_t cap = 0;
@@ -619,8 +639,10 @@ ORACLE_API void mirt_oracle_rasterise(const float *tris15, const uint8_t *culled
                 if (y < H && y >= 0 && zinv > out_depth[(size_t)y * W + x]) {     /* :606 */
                     size_t px = (size_t)y * W + x;
                     out_depth[px] = zinv;                                         /* :608 */
-                    st3(rgb + 3 * px, pixel_shader(p3, zinv, invrot, cam, lights7, nlights, ind, color, normal));
+                    float camdist;
+                    st3(rgb + 3 * px, pixel_shader(p3, zinv, invrot, cam, lights7, nlights, ind, color, normal, &camdist));
                     if (out_index) out_index[px] = ti;
+                    if (out_fd) out_fd[px] = camdist - focal_plane;                 /* :564-565 */
                 }
             }
         }
@@ -636,4 +658,40 @@ ORACLE_API void mirt_oracle_rasterise(const float *tris15, const uint8_t *culled
     }
     free(left); free(right); free(edge);
     if (!out_rgb) free(rgb);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* depth of field: the DOF_ENABLED branch of CalculateDOF (raytracer.cpp:613-640, rasteriser.cpp:494-513)   */
+
+/* rgb = pixelColours, fd = focalDistances (W*H, stride W).  Resolves rows [y0,y1) into out_xrgb: interior pixels get the
+ * blurred colour; border pixels are left alone, or zeroed when clear_border (the rasteriser's Update() painted the whole
+ * surface black).  Tap addresses are flat indices as in the reference; a flat index outside the frame is undefined
+ * behaviour there and contributes nothing here (documented divergence). */
+ORACLE_API void mirt_oracle_dof(const float *rgb, const float *fd, int W, int H, int K, int y0, int y1, int clear_border,
+                                uint32_t *out_xrgb, int pitch_words)
+{
+    const float totalPixels = (float)(K * K);                                    /* :615 */
+    const int zlo = (int)ceilf((float)K / -2.0f), zhi = (int)ceilf((float)K / 2.0f);   /* :624,626 */
+    const long long npx = (long long)W * H;
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < W; x++) {
+            if (!(x >= 1 && x < W - 1 && y >= 1 && y < H - 1)) {                 /* :618-620 */
+                if (clear_border) out_xrgb[(size_t)y * pitch_words + x] = 0u;
+                continue;
+            }
+            v3 fin = V(0, 0, 0);
+            const float f = fd[(size_t)y * W + x];
+            const float a = fabsf(f) < 1.0f ? fabsf(f) : 1.0f;                   /* std::min(abs(fd), 1.0f) */
+            for (int z = zlo; z < zhi; z++)
+                for (int z2 = zlo; z2 < zhi; z2++) {
+                    float weighting;
+                    if (z == 0 && z2 == 0) weighting = 1 - (a * ((totalPixels - 1) / totalPixels));   /* :629 */
+                    else weighting = a * (1.0f / totalPixels);                   /* :631 */
+                    const long long idx = (long long)(y + z) * W + (x + z2);     /* :634 */
+                    v3 c = V(0, 0, 0);
+                    if (idx >= 0 && idx < npx) c = ld3(rgb + 3 * idx);
+                    fin = add3(fin, scale3(c, weighting));
+                }
+            out_xrgb[(size_t)y * pitch_words + x] = pack_xrgb(fin);              /* PutPixelSDL :646 */
+        }
 }

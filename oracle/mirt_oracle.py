@@ -55,6 +55,9 @@ class Oracle:
                                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), f32p]
         lib.mirt_oracle_rasterise.argtypes = [f32p, _vp, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, _vp,
                                               C.c_int, f32p, _vp, _vp, _vp, _vp, C.c_int]
+        lib.mirt_oracle_rasterise_ex.argtypes = [f32p, _vp, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, _vp,
+                                                 C.c_int, f32p, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int]
+        lib.mirt_oracle_dof.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int]
         for name in ("mat3_inverse", "mat3_mul_vec", "vec_mul_mat3", "normalize", "cross"):
             getattr(lib, "mirt_oracle_" + name).argtypes = [f32p] * (2 if name in ("mat3_inverse", "normalize") else 3)
         lib.mirt_oracle_dot.restype = C.c_float
@@ -129,8 +132,18 @@ class Oracle:
                                            C.byref(x), C.byref(y), C.byref(z), p)
         return x.value, y.value, z.value, p
 
+    def dof(self, rgb, fd, K, clear_border=False, xrgb=None, y0=0, y1=None):
+        """CalculateDOF's blur + PutPixelSDL over rows [y0,y1); returns the surface words."""
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        fd = np.ascontiguousarray(fd, np.float32)
+        H, W = fd.shape
+        out = np.zeros((H, W), np.uint32) if xrgb is None else xrgb
+        self.lib.mirt_oracle_dof(rgb.reshape(-1), fd.reshape(-1), W, H, int(K), y0, H if y1 is None else y1,
+                                 1 if clear_border else 0, _ptr(out), W)
+        return out
+
     def rasterise(self, tris, culled, cam_pos, rot9, focal, W, H, lights, indirect=(0.2, 0.2, 0.2),
-                  want=("rgb", "index", "xrgb")):
+                  want=("rgb", "index", "xrgb"), focal_plane=0.0):
         tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 15)
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 7)
         culled = None if culled is None else np.ascontiguousarray(culled, np.uint8)
@@ -139,11 +152,12 @@ class Oracle:
             "rgb": np.zeros((H, W, 3), np.float32) if "rgb" in want else None,
             "index": np.full((H, W), -1, np.int32) if "index" in want else None,
             "xrgb": np.zeros((H, W), np.uint32) if "xrgb" in want else None,
+            "fd": np.zeros((H, W), np.float32) if "fd" in want else None,
         }
-        self.lib.mirt_oracle_rasterise(
+        self.lib.mirt_oracle_rasterise_ex(
             tris, _ptr(culled), len(tris), np.asarray(cam_pos, np.float32), np.ascontiguousarray(rot9, np.float32),
             float(focal), W, H, _ptr(lights) if len(lights) else None, len(lights), np.asarray(indirect, np.float32),
-            _ptr(out["depth"]), _ptr(out["rgb"]), _ptr(out["index"]), _ptr(out["xrgb"]), W)
+            float(focal_plane), _ptr(out["depth"]), _ptr(out["rgb"]), _ptr(out["index"]), _ptr(out["fd"]), _ptr(out["xrgb"]), W)
         return out
 
 
