@@ -10,6 +10,8 @@ Prints ONE JSON line (rank 0).  Workloads (BASELINE.json `configs`):
     raster4k     (configs[3]) rasteriser, Cornell box, 3840x2160
     cornell500   (configs[0]) the reference's own 500x500 case
     cornell1080soft16  configs[1] with the reference's 16-sample soft shadows switched on
+    cornell1080aa3     configs[1] with AA_SAMPLES = 3 supersampling
+    cornell1080dof8, raster4kdof8   configs[1] / configs[3] with the 8x8 depth-of-field blur
     soup1m8k     (configs[4]) 1M random triangles, 7680x4320 (meant for 8 GPUs)
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the frame is split into N bands of
 rows; every rank renders its band and the XRGB bands are gathered on rank 0 over RCCL ("scaling": "strong").
@@ -37,6 +39,9 @@ WORKLOADS = {
     "cornell1080": ("rt", ("cornell",), 1920, 1080, (0, 0, -2), 540.0, 1.0),
     "cornell500": ("rt", ("cornell",), 500, 500, (0, 0, -2), 250.0, 1.0),
     "cornell1080soft16": ("rt", ("cornell",), 1920, 1080, (0, 0, -2), 540.0, 1.0),   # + SOFT_SHADOWS_SAMPLES = 16
+    "cornell1080aa3": ("rt", ("cornell",), 1920, 1080, (0, 0, -2), 540.0, 1.0),      # + AA_SAMPLES = 3 (rank 2)
+    "cornell1080dof8": ("rt", ("cornell",), 1920, 1080, (0, 0, -2), 540.0, 1.0),     # + DOF_KERNEL_SIZE = 8, FOCAL_LENGTH = 1.3 (rank 3)
+    "raster4kdof8": ("raster", ("cornell",), 3840, 2160, (0, 0, -3), 2160.0, 1.01),  # + DOF_KERNEL_SIZE = 8, FOCAL_LENGTH = 1.9
     "soup100k": ("rt", ("soup", 1, 100000, 0.05), 1920, 1080, (0, 0, -2), 540.0, 1.0),
     "soup1m8k": ("rt", ("soup", 2, 1000000, 0.02), 7680, 4320, (0, 0, -2), 2160.0, 1.0),
     "raster4k": ("raster", ("cornell",), 3840, 2160, (0, 0, -3), 2160.0, 1.01),
@@ -66,7 +71,7 @@ def measured_traffic(workload, kernel_prefixes):
     return tot or None
 
 
-def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, samples=1, jitter=None):
+def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, samples=1, jitter=None, aa=1):
     """The oracle (CPU restatement, oracle/mirt_oracle.c) timed on this host's cores on a bounded sample of
     the same workload.  Test infrastructure: measured as a baseline, never used by the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -88,7 +93,7 @@ def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, sampl
     cores = min(cores, 64)                      # OpenMP over rows stops scaling long before 256 threads here
     centre = H // 2
     t0 = time.perf_counter()
-    soft = dict(samples=samples, jitter=jitter)
+    soft = dict(samples=samples, jitter=jitter, aa=aa)
     r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=centre, y1=centre + 1, threads=cores, want=("xrgb",), **soft)
     probe = max(time.perf_counter() - t0, 1e-4)
     rows = int(max(cores, min(H, budget_s / probe)))
@@ -96,7 +101,7 @@ def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, sampl
         t0 = time.perf_counter()
         r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, threads=cores, want=("xrgb",), **soft)
         dt = time.perf_counter() - t0
-        rays = W * H + r["nshadow"]
+        rays = W * H * aa * aa + r["nshadow"]
         sample = "full %dx%d frame" % (W, H)
     else:
         # one call over a contiguous band of `rows` rows around the image centre keeps all threads busy
@@ -105,7 +110,7 @@ def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, sampl
         t0 = time.perf_counter()
         r = o.raytrace(tris, cam, rot, focal, W, H, LIGHT, y0=ya, y1=yb, threads=cores, want=("xrgb",), **soft)
         dt = time.perf_counter() - t0
-        rays = W * (yb - ya) + r["nshadow"]
+        rays = W * (yb - ya) * aa * aa + r["nshadow"]
         sample = "rows %d..%d of %d (central band), per-ray rate" % (ya, yb - 1, H)
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample}
 
@@ -154,6 +159,10 @@ def main():
         soft_samples = 16
         soft_jitter = (LIGHT[:, 0:3] + (np.random.RandomState(1).rand(16, 3).astype(np.float32) - np.float32(0.5)) * np.float32(0.08)).astype(np.float32)
         mirt.set_soft_shadows(soft_samples, soft_jitter)
+    aa = 3 if args.workload.endswith("aa3") else 1
+    mirt.set_antialiasing(aa)
+    dof = 8 if args.workload.endswith("dof8") else 0
+    mirt.set_depth_of_field(dof, 1.3 if kind == "rt" else 1.9)
 
     steps = args.steps if args.steps is not None else (1000 if len(tris) < 1000 else 20)
     warmup = args.warmup if args.warmup is not None else (50 if len(tris) < 1000 else 3)
@@ -256,8 +265,8 @@ def main():
                 "metric": "Mrays/s (primary+shadow)", "unit": "Mrays/s", "dtype": "f32",
                 "value": round(rays_frame / (dt / steps) / 1e6, 3),
                 "config": {"workload": args.workload, "scene": "cornell-30" if scene[0] == "cornell" else "soup-%d-seed%d" % (scene[2], scene[1]),
-                           "triangles": int(len(tris)), "width": W, "height": H, "lights": 1, "soft_shadow_samples": soft_samples,
-                           "primary_rays": W * H, "shadow_rays": int(shadow_frame), "mode": ["auto", "brute", "binned"][st["mode_used"]],
+                           "triangles": int(len(tris)), "width": W, "height": H, "lights": 1, "soft_shadow_samples": soft_samples, "aa_samples": aa, "dof_kernel": dof,
+                           "primary_rays": W * H * aa * aa, "shadow_rays": int(shadow_frame), "mode": ["auto", "brute", "binned"][st["mode_used"]],
                            "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
             })
             kt = kernel_ms.get("trace", 0.0)
@@ -289,7 +298,7 @@ def main():
             out.update({
                 "metric": "frames/s (rasteriser)", "unit": "frames/s", "dtype": "f32", "value": round(steps / dt, 3),
                 "config": {"workload": args.workload, "scene": "cornell-30", "triangles": int(len(tris)), "visible_triangles": int((culled == 0).sum()),
-                           "width": W, "height": H, "lights": 1, "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
+                           "width": W, "height": H, "lights": 1, "dof_kernel": dof, "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
             })
             # algorithmic bytes per frame: clear 8/px + fragments x 8 + resolve read 8/px + XRGB write 4/px
             frag = 1.5 * px
@@ -302,7 +311,9 @@ def main():
                                    "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 PMC, bytes per frame)",
                                    "algorithmic_bytes": int(algo_bytes), "frame_kernel_ms": round(tot, 5)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, samples=soft_samples, jitter=soft_jitter)
+            out["cpu_baseline"] = cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, samples=soft_samples, jitter=soft_jitter, aa=aa)
+            if dof:
+                out["cpu_baseline"]["sample"] += "; per-pixel path only, the depth-of-field blur is not part of the CPU sample"
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -8,25 +8,232 @@
 //
 // The tap address is a FLAT index, exactly as in the reference: columns outside the row wrap into the neighbouring
 // rows.  Flat indices outside the frame read whatever lies next to the reference's global array (undefined
-// behaviour); here such taps contribute nothing (documented divergence).  One thread per pixel;
-// neighbouring lanes share their taps through L1/L2, the plane is read once from HBM.
+// behaviour); here such taps contribute nothing (documented divergence).
+//
+// The weights belong to the OUTPUT pixel and the sum is sequential, so partial sums cannot be shared between pixels
+// (a running box sum would round differently): every output needs its own K*K multiply-adds.  What can be shared is
+// the data: k_dof_tile stages a (32+K-1) x (64+K-1) tile of pixelColours in LDS; a thread owns eight
+// vertically adjacent outputs and walks the tile rows once, feeding each value it reads to every output whose window
+// holds that row -- each output still sees its taps in the reference's (z, z2) order.  HBM traffic is the
+// algorithmic 16 B read + 4 B written per pixel (plus the tile halo); the kernel is bound by its K*K*6 VALU
+// operations per pixel (no FMA: the reference multiplies, then adds).
+#include "dof.hpp"
+
+#include <utility>
 #include "mirt_math.hpp"
 
 namespace mirt {
 
-struct DofFrame {
-    const float *rgb;        // pixelColours, full-frame indexing, row stride W; rows [ry0, ry1) are valid
-    const float *fd;         // focalDistances, same indexing
-    int W, H;
-    int K;                   // DOF_KERNEL_SIZE
-    int y0, y1, row_origin;  // rows to resolve
-    int ry0, ry1;            // rows present in rgb/fd (the band plus its halo)
-    uint32_t *xrgb;
-    int pitch_words;
-    int clear_border;        // rasteriser: Update() painted the whole surface black (rasteriser.cpp:190), so border words become 0
-};
+namespace {
 
-__global__ __launch_bounds__(256) void k_dof(const DofFrame f)
+constexpr int DOF_TX = 64;            // outputs per tile row = one wavefront
+constexpr int DOF_WAVES = 4;
+constexpr int DOF_PY = 8;             // vertically adjacent outputs per thread
+constexpr int DOF_TY = DOF_WAVES * DOF_PY;
+constexpr int DOF_MAX_TILE_K = 16;
+typedef float f2 __attribute__((ext_vector_type(2)));
+static_assert(DOF_PY % 4 == 0, "outputs are paired for the packed arithmetic and fenced four at a time");    // larger kernels take k_dof_direct
+
+__device__ __forceinline__ int dof_zlo(int K) { return (int)ceilf((float)K / -2.0f); }
+__device__ __forceinline__ int dof_zhi(int K) { return (int)ceilf((float)K / 2.0f); }
+
+// Scheduling fence: everything that feeds the accumulators happens before it, no LDS read moves above it.
+__device__ __forceinline__ void dof_fence(v3 *fin, const float *row)
+{
+#pragma unroll
+    for (int p = 0; p < DOF_PY; p += 2)
+        asm volatile("" : "+v"(fin[p].x), "+v"(fin[p].y), "+v"(fin[p].z), "+v"(fin[p + 1].x), "+v"(fin[p + 1].y), "+v"(fin[p + 1].z)
+                     : "v"(row) : "memory");
+}
+
+__device__ __forceinline__ void dof_fence2(f2 *fxy, f2 *fz, const float *row)
+{
+#pragma unroll
+    for (int p = 0; p < DOF_PY; p += 4)
+        asm volatile("" : "+v"(fxy[p]), "+v"(fxy[p + 1]), "+v"(fxy[p + 2]), "+v"(fxy[p + 3]), "+v"(fz[p / 2]), "+v"(fz[p / 2 + 1])
+                     : "v"(row) : "memory");
+}
+
+// One tile row: z = zlo + (RR - p) for output p.  Everything that depends on (RR, c, p) is resolved at compile time.
+// fxy: (r, g) of each output; fz: b of outputs (2q, 2q+1); wo2: their off-centre weights; cur: the K taps of the
+// current tile row as they lie in memory.
+template <int RR, int KT>
+__device__ __forceinline__ void dof_row(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2], const f2 (&wo2)[DOF_PY / 2], const float (&wc)[DOF_PY],
+                                        const float (&wo)[DOF_PY], float (&cur)[3 * KT], const float *t0, int pitch)
+{
+    constexpr int ZC = KT / 2;                        // -ceil(KT / -2.0f): index of the centre tap
+    float nxt[3 * KT];
+    if constexpr (RR + 1 < DOF_PY + KT - 1) {
+        // the reads of row RR+1 are issued (volatile: they stay where they are written) before the arithmetic of row RR
+        typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
+        lds_vfloat *tn = (lds_vfloat *)(t0 + (RR + 1) * pitch);
+#pragma unroll
+        for (int i = 0; i < 3 * KT; i++) nxt[i] = tn[i];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < KT; c++) {
+        const f2 vxy = { cur[3 * c], cur[3 * c + 1] };
+        const float vz = cur[3 * c + 2];
+#pragma unroll
+        for (int p = 0; p < DOF_PY; p++) {
+            const int zi = RR - p;
+            if (zi < 0 || zi >= KT) continue;
+            const float w = (zi == ZC && c == ZC) ? wc[p] : wo[p];
+            fxy[p] = fxy[p] + vxy * (f2){ w, w };                         // finalColour += colour * weighting (r, g)
+        }
+#pragma unroll
+        for (int q = 0; q < DOF_PY / 2; q++) {
+            const int z0 = RR - 2 * q, z1 = z0 - 1;
+            const bool a0 = z0 >= 0 && z0 < KT, a1 = z1 >= 0 && z1 < KT;
+            const bool c0 = z0 == ZC && c == ZC, c1 = z1 == ZC && c == ZC;
+            if (a0 && a1) {
+                const f2 w = (c0 || c1) ? (f2){ c0 ? wc[2 * q] : wo[2 * q], c1 ? wc[2 * q + 1] : wo[2 * q + 1] } : wo2[q];
+                fz[q] = fz[q] + (f2){ vz, vz } * w;                       // b of outputs 2q and 2q+1
+            } else if (a0) {
+                fz[q].x = fz[q].x + vz * (c0 ? wc[2 * q] : wo[2 * q]);
+            } else if (a1) {
+                fz[q].y = fz[q].y + vz * (c1 ? wc[2 * q + 1] : wo[2 * q + 1]);
+            }
+        }
+    }
+    dof_fence2(fxy, fz, t0);
+    if constexpr (RR + 1 < DOF_PY + KT - 1) {
+#pragma unroll
+        for (int i = 0; i < 3 * KT; i++) cur[i] = nxt[i];
+    }
+}
+
+template <int KT, int... RR>
+__device__ __forceinline__ void dof_rows(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2], const f2 (&wo2)[DOF_PY / 2], const float (&wc)[DOF_PY],
+                                         const float (&wo)[DOF_PY], float (&cur)[3 * KT], const float *t0, int pitch,
+                                         std::integer_sequence<int, RR...>)
+{
+    (dof_row<RR, KT>(fxy, fz, wo2, wc, wo, cur, t0, pitch), ...);
+}
+
+// One pixelColours element by flat index, 0 outside the frame or outside the rows this call rendered.
+__device__ __forceinline__ float dof_fetch(const DofFrame &f, long long flat_px, int ch)
+{
+    if (flat_px < 0 || flat_px >= (long long)f.W * f.H) return 0.0f;
+    const int row = (int)(flat_px / f.W);
+    if (row < f.ry0 || row >= f.ry1) return 0.0f;     // cannot happen for a halo of reach rows; kept as a guard
+    return f.rgb[3 * flat_px + ch];
+}
+
+// KT > 0: kernel size known at compile time (loops unrolled); KT == 0: f.K at run time (<= DOF_MAX_TILE_K).
+template <int KT>
+__global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame f)
+{
+    extern __shared__ float tile[];                   // [TR][TC][3]: pixelColours as it lies in memory
+    const int K = KT > 0 ? KT : f.K;
+    const int zlo = dof_zlo(K);
+    const int TR = DOF_TY + K - 1;                    // tile rows
+    const int pitch = (DOF_TX + K - 1) * 3;           // floats per tile row
+    const int x0 = blockIdx.x * DOF_TX, ty0 = f.y0 + blockIdx.y * DOF_TY;
+
+    // stage: tile(r, c) = pixelColours[(ty0 + zlo + r) * W + (x0 + zlo + c)] by FLAT index, as the reference addresses
+    // it (a column outside the row wraps into the neighbouring row); 0 outside the frame / the rows rendered.
+    // Every tile row is one contiguous run of floats: a straight copy, one wave per row.
+    const long long lo = 3LL * max(0, f.ry0) * f.W, hi = 3LL * min(f.H, f.ry1) * f.W;
+    if constexpr (KT > 0) {
+        // all loads of the thread first, then all LDS stores: one round trip to memory instead of one per element
+        constexpr int ROWS = (DOF_TY + KT - 1 + DOF_WAVES - 1) / DOF_WAVES, COLS = ((DOF_TX + KT - 1) * 3 + DOF_TX - 1) / DOF_TX;
+        float v[ROWS][COLS];
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) {
+            const int r = threadIdx.y + j * DOF_WAVES;
+            const long long src = 3 * ((long long)(ty0 + zlo + r) * f.W + (x0 + zlo));
+#pragma unroll
+            for (int k = 0; k < COLS; k++) {
+                const int i = threadIdx.x + k * DOF_TX;
+                const long long s = src + i;
+                v[j][k] = (r < TR && i < pitch && s >= lo && s < hi) ? f.rgb[s] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; j++) {
+            const int r = threadIdx.y + j * DOF_WAVES;
+#pragma unroll
+            for (int k = 0; k < COLS; k++) {
+                const int i = threadIdx.x + k * DOF_TX;
+                if (r < TR && i < pitch) tile[r * pitch + i] = v[j][k];
+            }
+        }
+    } else {
+        for (int r = threadIdx.y; r < TR; r += DOF_WAVES) {
+            const long long src = 3 * ((long long)(ty0 + zlo + r) * f.W + (x0 + zlo));
+            for (int i = threadIdx.x; i < pitch; i += DOF_TX) {
+                const long long s = src + i;
+                tile[r * pitch + i] = (s >= lo && s < hi) ? f.rgb[s] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int x = x0 + threadIdx.x;
+    const int yb = ty0 + threadIdx.y * DOF_PY;        // first of this thread's rows
+    if (x >= f.W) return;
+    const float totalPixels = (float)(K * K);                                 // :615
+    float wc[DOF_PY], wo[DOF_PY];
+    v3 fin[DOF_PY];
+#pragma unroll
+    for (int p = 0; p < DOF_PY; p++) {
+        const int y = yb + p;
+        float fdc = 0.0f;
+        if (y < f.y1) fdc = f.fd[(size_t)y * f.W + x];
+        const float a = fminf(fabsf(fdc), 1.0f);                              // min(abs(focalDistances[..]), 1.0f)
+        wc[p] = 1 - (a * ((totalPixels - 1) / totalPixels));                  // :629
+        wo[p] = a * (1.0f / totalPixels);                                     // :631
+        fin[p] = V3(0.0f, 0.0f, 0.0f);
+    }
+    // lanes read with a stride of 3 floats: odd, so the 64 lanes of a read fall into 64 different banks
+    const float *t0 = tile + (threadIdx.y * DOF_PY) * pitch + threadIdx.x * 3;
+    if constexpr (KT > 0) {
+        // Software pipeline over tile rows: the reads of row rr+1 are issued (volatile: they stay where they are
+        // written) before the arithmetic of row rr, which covers the LDS latency.  Without this the scheduler either
+        // hoists every read (280 VGPRs, 1 wave per SIMD) or sinks each read to just before its use and stalls on it.
+        // The arithmetic is packed FP32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE multiplies or adds per issue slot, the
+        // same roundings as the scalar forms): red and green of one output share an instruction, and the blues of two
+        // vertically adjacent outputs share one.
+        f2 fxy[DOF_PY], fz[DOF_PY / 2], wo2[DOF_PY / 2];
+#pragma unroll
+        for (int p = 0; p < DOF_PY; p++) fxy[p] = (f2){ 0.0f, 0.0f };
+#pragma unroll
+        for (int q = 0; q < DOF_PY / 2; q++) { fz[q] = (f2){ 0.0f, 0.0f }; wo2[q] = (f2){ wo[2 * q], wo[2 * q + 1] }; }
+        float cur[3 * KT];
+#pragma unroll
+        for (int i = 0; i < 3 * KT; i++) cur[i] = t0[i];
+        dof_rows<KT>(fxy, fz, wo2, wc, wo, cur, t0, pitch, std::make_integer_sequence<int, DOF_PY + KT - 1>());
+#pragma unroll
+        for (int p = 0; p < DOF_PY; p++) fin[p] = V3(fxy[p].x, fxy[p].y, (p & 1) ? fz[p / 2].y : fz[p / 2].x);
+    } else {
+        for (int rr = 0; rr < DOF_PY + K - 1; rr++) {
+            const float *tr = t0 + rr * pitch;
+            for (int c = 0; c < K; c++) {
+                const v3 v = V3(tr[3 * c], tr[3 * c + 1], tr[3 * c + 2]);
+#pragma unroll
+                for (int p = 0; p < DOF_PY; p++) {
+                    const int zi = rr - p;
+                    if (zi < 0 || zi >= K) continue;
+                    const float w = (zi == -zlo && c == -zlo) ? wc[p] : wo[p];
+                    fin[p] = add3(fin[p], scale3(v, w));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < DOF_PY; p++) {
+        const int y = yb + p;
+        if (y >= f.y1) break;
+        uint32_t *out = f.xrgb + (size_t)(y - f.row_origin) * f.pitch_words + x;
+        if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1) *out = pack_xrgb(fin[p]);   // interior only (:618-620), PutPixelSDL (:646)
+        else if (f.clear_border) *out = 0u;
+    }
+}
+
+// Any kernel size: one thread per pixel, taps through L1/L2.
+__global__ __launch_bounds__(256) void k_dof_direct(const DofFrame f)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = f.y0 + blockIdx.y;
@@ -36,26 +243,41 @@ __global__ __launch_bounds__(256) void k_dof(const DofFrame f)
         return;
     }
     const float totalPixels = (float)(f.K * f.K);                             // :615
-    const int zlo = (int)ceilf((float)f.K / -2.0f), zhi = (int)ceilf((float)f.K / 2.0f);
+    const int zlo = dof_zlo(f.K), zhi = dof_zhi(f.K);
     const float fdc = f.fd[(size_t)y * f.W + x];
-    const float a = fminf(fabsf(fdc), 1.0f);                                  // min(abs(focalDistances[..]), 1.0f)
+    const float a = fminf(fabsf(fdc), 1.0f);
     const float w_centre = 1 - (a * ((totalPixels - 1) / totalPixels));       // :629
     const float w_other = a * (1.0f / totalPixels);                           // :631
-    const long long npx = (long long)f.W * f.H;
     v3 fin = V3(0.0f, 0.0f, 0.0f);
     for (int z = zlo; z < zhi; z++) {
         for (int z2 = zlo; z2 < zhi; z2++) {
             const float w = (z == 0 && z2 == 0) ? w_centre : w_other;
             const long long idx = (long long)(y + z) * f.W + (x + z2);        // flat index, as in the reference (:634)
-            v3 c = V3(0.0f, 0.0f, 0.0f);
-            if (idx >= 0 && idx < npx) {
-                const int row = (int)(idx / f.W);                             // within the rendered band + halo by construction
-                if (row >= f.ry0 && row < f.ry1) c = ld3(f.rgb + 3 * idx);
-            }
-            fin = add3(fin, scale3(c, w));                                    // finalColour += colour * weighting
+            const v3 c = V3(dof_fetch(f, idx, 0), dof_fetch(f, idx, 1), dof_fetch(f, idx, 2));
+            fin = add3(fin, scale3(c, w));
         }
     }
     f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(fin);  // PutPixelSDL (:646)
+}
+
+size_t dof_tile_lds_bytes(int K)
+{
+    return (size_t)(DOF_TY + K - 1) * (DOF_TX + K - 1) * 3 * sizeof(float);
+}
+
+}  // namespace
+
+void launch_dof(const DofFrame &d, hipStream_t stream)
+{
+    const int rows = d.y1 - d.y0;
+    if (rows <= 0 || d.W <= 0) return;
+    if (d.K <= DOF_MAX_TILE_K) {
+        const dim3 grid((d.W + DOF_TX - 1) / DOF_TX, (rows + DOF_TY - 1) / DOF_TY), block(DOF_TX, DOF_WAVES);
+        if (d.K == 8) hipLaunchKernelGGL(k_dof_tile<8>, grid, block, dof_tile_lds_bytes(8), stream, d);
+        else hipLaunchKernelGGL(k_dof_tile<0>, grid, block, dof_tile_lds_bytes(d.K), stream, d);
+    } else {
+        hipLaunchKernelGGL(k_dof_direct, dim3((d.W + 255) / 256, rows), dim3(256), 0, stream, d);
+    }
 }
 
 }  // namespace mirt

@@ -1,6 +1,7 @@
 // mirt_capi.hip -- the C-ABI of include/mirt.h on top of the HIP kernels.  Owns the device scene, the
 // library stream, staging buffers and the per-call statistics.  No CPU fallback: without a gfx950 device
 // every compute entry point returns MIRT_ERR_NO_DEVICE.
+#include "dof.hpp"
 #include "rt_common.hpp"
 #include "raster_common.hpp"
 #include "rt_binned.hpp"
@@ -28,18 +29,6 @@ struct RtTileFrame {
     unsigned long long *clear_hits;
 };
 template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
-struct DofFrame {
-    const float *rgb;
-    const float *fd;
-    int W, H;
-    int K;
-    int y0, y1, row_origin;
-    int ry0, ry1;
-    uint32_t *xrgb;
-    int pitch_words;
-    int clear_border;
-};
-__global__ void k_dof(const DofFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
@@ -598,9 +587,9 @@ int render_with_dof(const mirt_view *view, int y0, int y1, int row_origin, void 
         d.rgb = rgb; d.fd = fd; d.W = W; d.H = H; d.K = K;
         d.y0 = y0; d.y1 = y1; d.row_origin = row_origin; d.ry0 = ry0; d.ry1 = ry1;
         d.xrgb = static_cast<uint32_t *>(d_xrgb); d.pitch_words = pitch_bytes / 4; d.clear_border = clear_border ? 1 : 0;
-        if (g.profiling) { (void)hipEventRecord(g.ev[EV_K0 + 2 * MIRT_K_SHADE], g.stream); g.ev_used[MIRT_K_SHADE] = true; }
-        hipLaunchKernelGGL(k_dof, dim3((W + 255) / 256, y1 - y0), dim3(256), 0, g.stream, d);
-        if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * MIRT_K_SHADE + 1], g.stream);
+        if (g.profiling) { (void)hipEventRecord(g.ev[EV_K0 + 2 * MIRT_K_DOF], g.stream); g.ev_used[MIRT_K_DOF] = true; }
+        launch_dof(d, g.stream);
+        if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * MIRT_K_DOF + 1], g.stream);
         HIP_TRY(hipGetLastError());
         const size_t rows = (size_t)(y1 - y0), off = (size_t)(y0 - ry0) * W, uoff = (size_t)y0 * W;
         if (user_rgb) HIP_TRY(hipMemcpyAsync((float *)user_rgb + 3 * uoff, g.d_dof_rgb + 3 * off, rows * W * 12, hipMemcpyDeviceToDevice, g.stream));

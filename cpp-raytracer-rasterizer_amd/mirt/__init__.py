@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmirt.so")
 
 MAX_LIGHTS = 32
 RT_AUTO, RT_BRUTE, RT_BINNED = 0, 1, 2
-KERNEL_NAMES = ("prep", "bin", "trace", "shade", "raster_setup", "raster_frag", "raster_resolve", "clear")
+KERNEL_NAMES = ("prep", "bin", "trace", "dof", "raster_setup", "raster_frag", "raster_resolve", "clear")
 
 # every symbol include/mirt.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (

@@ -81,7 +81,7 @@ typedef struct mirt_stats {
 } mirt_stats;
 
 /* indices into mirt_stats.kernel_ms */
-enum { MIRT_K_PREP = 0, MIRT_K_BIN = 1, MIRT_K_TRACE = 2, MIRT_K_SHADE = 3,
+enum { MIRT_K_PREP = 0, MIRT_K_BIN = 1, MIRT_K_TRACE = 2, MIRT_K_DOF = 3,
        MIRT_K_RASTER_SETUP = 4, MIRT_K_RASTER_FRAG = 5, MIRT_K_RASTER_RESOLVE = 6, MIRT_K_CLEAR = 7 };
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
