@@ -25,10 +25,10 @@ struct RtTileFrame {
     RtFrame f;
     BinFrameDesc cam;
     int tiles_x, tiles_y;
-    int tiles_per_wave;
     unsigned long long *clear_hits;
 };
 template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
+template <int TW> __global__ void k_rt_tile2(const RtTileFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
 struct RtBinnedFrame {
     RtFrame f;
@@ -67,7 +67,12 @@ struct Ctx {
     bool init = false;
     bool profiling = false;
     int device = -1;
-    hipStream_t stream = nullptr;
+    int cu_count = 256;                          // multiProcessorCount of the device
+    hipStream_t stream = nullptr;                // the stream of the current call (one of streams[])
+    hipStream_t streams[2] = { nullptr, nullptr };
+    int in_flight = 1;                           // frames that may be in flight at once (mirt_set_frames_in_flight)
+    uint64_t frame_no = 0;                       // device calls so far; call i runs on streams[i & 1] when in_flight == 2
+    hipEvent_t ev_chain = nullptr;               // orders a call after the previous one when it must not overlap it
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_used[8] = {};
 
@@ -81,9 +86,10 @@ struct Ctx {
     float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
     uint32_t *d_flags = nullptr;                 // [0] = unsafe flag
     unsigned long long *d_hits = nullptr;        // the hit-counter buffer of the current frame (one of d_hits2)
-    unsigned long long *d_hits2[2] = { nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
-    bool hits_clean[2] = { false, false };       // buffer is all zero (the tile kernel clears the other one itself)
+    unsigned long long *d_hits2[4] = { nullptr, nullptr, nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
+    bool hits_clean[4] = { false, false, false, false };   // buffer is all zero (the tile kernel clears the one two frames ahead itself)
     int hits_cur = 0;
+    int hits_tog[2] = { 0, 0 };
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
     int soft_samples = 1;                        // soft-shadow samples per light (1 = hard shadows)
@@ -180,10 +186,33 @@ int check_view(const mirt_view *v, const mirt_light *lights, int nlights, const 
 }
 
 void k_begin(int k) { if (g.profiling) { (void)hipEventRecord(g.ev[EV_K0 + 2 * k], g.stream); g.ev_used[k] = true; } }
+// Waits for every call enqueued so far (both streams).
+hipError_t sync_all()
+{
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2; i++)
+        if (g.streams[i]) { const hipError_t r = hipStreamSynchronize(g.streams[i]); if (r != hipSuccess) e = r; }
+    return e;
+}
+
 void k_end(int k) { if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * k + 1], g.stream); }
 
-void call_begin()
+// Every device call starts here.  With two frames in flight the calls alternate between two streams, so frame i+1 is
+// dispatched while frame i still drains (no dispatch gap, no idle tail).  A call that touches library state shared
+// between frames (origin tables, bins, raster scratch, the depth-of-field planes) is `self_contained == false` and is
+// ordered after the previous call; the tile ray tracer keeps everything in LDS and its hit counters rotate through
+// four buffers, so consecutive frames of it overlap freely.
+void call_begin(bool self_contained = false)
 {
+    if (g.in_flight == 2) {
+        hipStream_t prev = g.stream;
+        g.stream = g.streams[g.frame_no & 1];
+        if (!self_contained && prev != g.stream) {
+            (void)hipEventRecord(g.ev_chain, prev);
+            (void)hipStreamWaitEvent(g.stream, g.ev_chain, 0);
+        }
+    }
+    g.frame_no++;
     memset(&g.stats, 0, sizeof g.stats);
     memset(g.ev_used, 0, sizeof g.ev_used);
     (void)hipEventRecord(g.ev[EV_CALL0], g.stream);
@@ -263,15 +292,6 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         g.light_tab_lights = light_positions;
     }
 
-    call_begin();
-    g.pending_is_rt = true;
-    g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0) * (uint64_t)((g.aa > 1 ? g.aa : 1) * (g.aa > 1 ? g.aa : 1));
-    g.pending_nlights = light_positions;
-    g.stats.mode_used = MIRT_RT_BRUTE;
-    g.pending_empty = (y1 == y0);
-    g.pending_counted = false;
-    if (y1 == y0) { call_end(); return MIRT_OK; }
-
     RtFrame f;
     memset(&f, 0, sizeof f);
     f.tris15 = g.d_tris;
@@ -301,7 +321,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         const float *pos = samples > 1 ? g.soft_pos + 3 * j : lights[k].pos;
         memcpy(f.lpos[j], pos, 12);
         memcpy(origins + 3 * (j + 1), pos, 12);
-        for (int c = 0; c < 3; c++) f.lcol[j][c] = lights[k].color[c] * lights[k].intensity;   // raytracer.cpp:282
+        // P = (color * intensity) / samples (raytracer.cpp:282, :296): uniform per light, so the division happens once here
+        // (host float division is the same IEEE operation the kernels would run per pixel)
+        for (int c = 0; c < 3; c++) f.lcol[j][c] = (lights[k].color[c] * lights[k].intensity) / (float)f.samples;
     }
     nlights = npos;            // from here on "lights" means light positions
     memcpy(f.indirect, indirect, 12);
@@ -312,11 +334,6 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     f.index = static_cast<int32_t *>(d_index);
     f.fd = static_cast<float *>(d_fd);
     f.focal_plane = g.dof_focal;
-    // hit counters: two buffers used alternately so that a kernel can clear the one the NEXT frame will use
-    g.hits_cur ^= 1;
-    g.d_hits = g.d_hits2[g.hits_cur];
-    f.hit_count = g.d_hits;
-
     // The pre-reject filter is proven for finite, moderate operands only (rt_common.hpp); anything else
     // (absurd coordinates, NaN/Inf) renders through the exact-only path.  Ray directions of the primary
     // rays are bounded by 3 * max|rot| * max(W, H, |focal|).
@@ -341,25 +358,59 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     // triangle (rt_tile.hip).  Needs operands inside the filter's proven range, like binning does.
     static const int tile_w = [] { const char *e = getenv("MIRT_TILE_W"); int w = e ? atoi(e) : 16; return (w == 8 || w == 16 || w == 64) ? w : 0; }();
     const size_t tile_lds = (size_t)g.n * 16 * (12 + 3 * nlights);
-    if (!binned && safe && tile_w && g.n <= 64 && tile_lds <= 64 * 1024) {
+    const bool tile_path = !binned && safe && tile_w && g.n <= 64 && tile_lds <= 64 * 1024;
+
+    // The tile kernel reads only the scene and writes only the caller's planes and its own hit counters, so frames
+    // of it may overlap (call_begin); with depth of field the planes are the library's own and frames must not.
+    call_begin(tile_path && d_fd == nullptr);
+    g.pending_is_rt = true;
+    g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0) * (uint64_t)((g.aa > 1 ? g.aa : 1) * (g.aa > 1 ? g.aa : 1));
+    g.pending_nlights = light_positions;
+    g.stats.mode_used = MIRT_RT_BRUTE;
+    g.pending_empty = (y1 == y0);
+    g.pending_counted = false;
+    if (y1 == y0) { call_end(); return MIRT_OK; }
+    // hit counters: every stream owns two buffers used alternately, so that a kernel can clear the one the NEXT frame
+    // on its stream will use
+    {
+        const int si = (g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0;
+        g.hits_tog[si] ^= 1;
+        g.hits_cur = si + 2 * g.hits_tog[si];
+    }
+    g.d_hits = g.d_hits2[g.hits_cur];
+    f.hit_count = g.d_hits;
+
+    if (tile_path) {
         RtTileFrame tf;
         memset(&tf, 0, sizeof tf);
         tf.f = f;
         tf.cam = make_camera_frame(view, y0, y1, g.aa);
-        const int th = 64 / tile_w;
-        tf.tiles_x = (view->width + tile_w - 1) / tile_w;
+        // two pixels per lane (packed FP32, rt_tile.hip) unless supersampling is on; MIRT_TILE_PX=1 keeps one
+        static const int tile_px = [] { const char *e = getenv("MIRT_TILE_PX"); return (e && atoi(e) == 1) ? 1 : 2; }();
+        const bool two = f.aa <= 1 && tile_px == 2 && (tile_w == 16 || tile_w == 64);
+        const int tw = two ? (tile_w == 64 ? 32 : 16) : tile_w;
+        const int th = (two ? 128 : 64) / tw;
+        tf.tiles_x = (view->width + tw - 1) / tw;
         tf.tiles_y = (rows + th - 1) / th;
         const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
-        tf.tiles_per_wave = (int)std::min<long long>(16, std::max<long long>(1, ntiles / (4 * 2048)));
-        const unsigned blocks = (unsigned)((ntiles + 4LL * tf.tiles_per_wave - 1) / (4LL * tf.tiles_per_wave));
+        // Workgroups of 4 waves, MIRT_TILE_WGS > 0: that many workgroups per CU, waves stride over the tiles; default: one
+        // workgroup per 4 tiles.  Tile cost varies several-fold (candidates, shadowed or lit), and the hardware's dynamic
+        // workgroup dispatch balances that better than any static assignment (measured on the Cornell box at 1080p:
+        // 40.5 us with one tile per wave, 46 us with a resident grid striding over the tiles, 49 us with 3 tiles per wave).
+        static const int tile_wgs_per_cu = [] { const char *e = getenv("MIRT_TILE_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 8) ? v : 0; }();
+        static const int tile_waves = [] { const char *e = getenv("MIRT_TILE_WAVES"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 4; }();
+        const int wpb = two ? tile_waves : 4;               // waves per workgroup
+        const unsigned blocks = (unsigned)(tile_wgs_per_cu ? std::min<long long>((ntiles + wpb - 1) / wpb, (long long)g.cu_count * tile_wgs_per_cu) : (ntiles + wpb - 1) / wpb);
         if (!g.hits_clean[g.hits_cur])
             HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
         g.hits_clean[g.hits_cur] = false;
         g.pending_counted = true;
-        tf.clear_hits = g.d_hits2[g.hits_cur ^ 1];       // zeroed by this launch for the next frame: no memset node per frame
-        g.hits_clean[g.hits_cur ^ 1] = true;
+        tf.clear_hits = g.d_hits2[g.hits_cur ^ 2];       // zeroed by this launch for the next frame on this stream: no memset node per frame
+        g.hits_clean[g.hits_cur ^ 2] = true;
         k_begin(MIRT_K_TRACE);
         if (f.aa > 1) hipLaunchKernelGGL((k_rt_tile<16, true>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        else if (two && tw == 16) hipLaunchKernelGGL((k_rt_tile2<16>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
+        else if (two) hipLaunchKernelGGL((k_rt_tile2<32>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
         else if (tile_w == 8) hipLaunchKernelGGL((k_rt_tile<8, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
         else if (tile_w == 16) hipLaunchKernelGGL((k_rt_tile<16, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
         else hipLaunchKernelGGL((k_rt_tile<64, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
@@ -626,12 +677,17 @@ extern "C" int mirt_init(int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(MIRT_ERR_NO_DEVICE, "device %d is %s; the kernels in this library are built for gfx950 (MI355X) only", device, prop.gcnArchName);
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&g.streams[i], hipStreamNonBlocking));
+    g.stream = g.streams[0];
+    g.in_flight = 1;
+    g.frame_no = 0;
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_chain, hipEventDisableTiming));
     for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev[i]));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_flags), 16));
     HIP_TRY(hipMemset(g.d_flags, 0, 16));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 4; i++) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits2[i]), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
         HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
         g.hits_clean[i] = true;
@@ -646,15 +702,16 @@ extern "C" void mirt_shutdown(void)
 {
     if (!g.init) return;
     (void)hipSetDevice(g.device);
-    (void)hipStreamSynchronize(g.stream);
+    for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
-                     (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
+                     (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
                      (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries,
                      (void *)g.d_dof_rgb, (void *)g.d_dof_fd, (void *)g.d_dof_xrgb, (void *)g.d_dof_index, (void *)g.d_dof_zinv })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
-    if (g.stream) (void)hipStreamDestroy(g.stream);
+    if (g.ev_chain) (void)hipEventDestroy(g.ev_chain);
+    for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
     g = Ctx();
 }
 
@@ -670,11 +727,27 @@ extern "C" int mirt_sync(void)
 {
     int rc;
     if ((rc = need_init())) return rc;
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(sync_all());
     return MIRT_OK;
 }
 
-extern "C" void *mirt_stream(void) { return g.init ? (void *)g.stream : nullptr; }
+// The stream the NEXT device call will run on (with two frames in flight the calls alternate between two streams).
+extern "C" void *mirt_stream(void)
+{
+    if (!g.init) return nullptr;
+    return (void *)(g.in_flight == 2 ? g.streams[g.frame_no & 1] : g.stream);
+}
+
+extern "C" int mirt_set_frames_in_flight(int frames)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (frames < 1 || frames > 2) return fail(MIRT_ERR_INVALID_ARGUMENT, "frames in flight must be 1 or 2, not %d", frames);
+    HIP_TRY(sync_all());
+    g.in_flight = frames;
+    if (frames == 1) g.stream = g.streams[0];
+    return MIRT_OK;
+}
 
 // ---- scene ------------------------------------------------------------------------------------------
 
@@ -683,7 +756,7 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     int rc;
     if ((rc = need_init())) return rc;
     if (!tris15 || n < 1) return fail(MIRT_ERR_INVALID_ARGUMENT, "scene needs at least one triangle (n = %d)", n);
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(sync_all());
     g.n = 0;
     if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
     if ((rc = dev_realloc(&g.d_culled, (size_t)n))) return rc;
@@ -707,6 +780,7 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
     if ((rc = need_init())) return rc;
     if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
     if (n != g.n) return fail(MIRT_ERR_INVALID_ARGUMENT, "cull array has %d entries, scene has %d triangles", n, g.n);
+    HIP_TRY(sync_all());
     if (culled) HIP_TRY(hipMemcpyAsync(g.d_culled, culled, (size_t)n, hipMemcpyHostToDevice, g.stream));
     else HIP_TRY(hipMemsetAsync(g.d_culled, 0, (size_t)n, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));

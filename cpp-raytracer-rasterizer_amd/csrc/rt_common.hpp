@@ -113,7 +113,7 @@ struct RtFrame {
     int aa;                     // realSamples of Draw(): AA_SAMPLES when AA_ENABLED, else 1 (raytracer.cpp:37-38,549-554)
     int samples;                // soft-shadow samples per light (SOFT_SHADOWS_SAMPLES, raytracer.cpp:41,272-275); 1 = off
     float lpos[MIRT_MAX_LIGHTS][3];
-    float lcol[MIRT_MAX_LIGHTS][3];   // lights[k].color * lights[k].intensity (raytracer.cpp:282)
+    float lcol[MIRT_MAX_LIGHTS][3];   // P of DirectLight: lights[k].color * lights[k].intensity / samples (raytracer.cpp:282, :296)
     float indirect[3];
     int y0, y1, row_origin;
     uint32_t *xrgb;
@@ -193,7 +193,7 @@ __device__ __forceinline__ v3 light_term(const RtFrame &f, int k, v3 hit, v3 nDi
     const v3 L = ld3(f.lpos[k]);
     const float rr = distance3(hit, L);
     const float A = sphere_area(rr);
-    const v3 P = div3s(ld3(f.lcol[k]), (float)f.samples);   // P = lightColor /= (float)samples (:296)
+    const v3 P = ld3(f.lcol[k]);                       // P = lightColor /= (float)samples (:296), divided on the host
     const v3 rd = normalize3(sub3(L, hit));
     const v3 B = div3s(P, A);
     const float d = dot3(rd, nDir);

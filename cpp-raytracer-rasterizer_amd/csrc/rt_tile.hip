@@ -13,6 +13,7 @@
 // been accepted by any ray of the wave).  Per-triangle normalised normals and colours sit in LDS too, and each
 // workgroup renders several tiles per wave so the table build is amortised.
 #include "rt_binned.hpp"
+#include "mirt_math2.hpp"
 
 #include <float.h>
 
@@ -22,7 +23,6 @@ struct RtTileFrame {
     RtFrame f;
     BinFrameDesc cam;        // camera ray family (P0, Pu, Pv, dmax); bins are not used, only the edge functions
     int tiles_x, tiles_y;    // tiles in the band
-    int tiles_per_wave;
     unsigned long long *clear_hits;   // the OTHER hit-counter buffer: zeroed here for the next frame (saves a memset launch)
 };
 
@@ -204,19 +204,22 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
 
-template <int TW, bool AA>
-__global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
+// LDS tables of a workgroup: origin rows of the camera and of every light position, geometry, the camera-frame edge
+// functions and the shading constants of every triangle.
+struct TileTables { float4 *cam, *geo, *fns, *shade, *light; };
+
+__device__ __forceinline__ TileTables tile_tables_build(const RtTileFrame &tf, float4 *s_all)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 s_all[];
     const RtFrame &f = tf.f;
     const int n = f.n;
-    float4 *s_cam = s_all;                       // 3 rows per triangle
-    float4 *s_geo = s_cam + 3 * n;               // 3
-    float4 *s_fns = s_geo + 3 * n;               // 4: the camera-frame edge functions n, p, q, s
-    float4 *s_shade = s_fns + 4 * n;             // 2: {normalize(normal), -}, {color, -}
-    float4 *s_light = s_shade + 2 * n;           // nlights x 3 rows per triangle
-
-    for (int t = threadIdx.x; t < n; t += 256) {
+    TileTables tb;
+    tb.cam = s_all;                       // 3 rows per triangle
+    tb.geo = tb.cam + 3 * n;               // 3
+    tb.fns = tb.geo + 3 * n;               // 4: the camera-frame edge functions n, p, q, s
+    tb.shade = tb.fns + 4 * n;             // 2: {normalize(normal), -}, {color, -}
+    tb.light = tb.shade + 2 * n;           // nlights x 3 rows per triangle
+    float4 *s_cam = tb.cam, *s_geo = tb.geo, *s_fns = tb.fns, *s_shade = tb.shade, *s_light = tb.light;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
         const float *t15 = f.tris15 + (size_t)15 * t;
         const OriginRow r = make_origin_row(t15, ld3(f.cam));
         s_cam[3 * t] = r.r0; s_cam[3 * t + 1] = r.r1; s_cam[3 * t + 2] = r.r2;
@@ -241,17 +244,219 @@ __global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
     __syncthreads();
 
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < HIT_SHARDS * HIT_SHARD_STRIDE; i += 256) tf.clear_hits[i] = 0ull;
+        for (int i = threadIdx.x; i < HIT_SHARDS * HIT_SHARD_STRIDE; i += blockDim.x) tf.clear_hits[i] = 0ull;
 
-    const int wave = threadIdx.x >> 6;
+    return tb;
+}
+
+template <int TW, bool AA>
+__global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_all[];
+    const TileTables tab = tile_tables_build(tf, s_all);
+    const float4 *s_cam = tab.cam, *s_geo = tab.geo, *s_fns = tab.fns, *s_shade = tab.shade, *s_light = tab.light;
+    // one tile per wave when the grid covers the frame (the default, see mirt_capi.hip); a smaller grid strides
     const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
-    const long long first = ((long long)blockIdx.x * 4 + wave) * tf.tiles_per_wave;
-    for (int i = 0; i < tf.tiles_per_wave; i++) {
-        const long long tile = first + i;
-        if (tile >= ntiles) break;
+    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * 4)
         tile_body<TW, AA>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), s_cam, s_geo, s_fns, s_shade, s_light);
+}
+
+
+// ---- two pixels per lane -------------------------------------------------------------------------------------------
+// The same tile algorithm with a wave owning TW x (128/TW) pixels: lane l carries pixel (lx, ly) and the pixel
+// 64/TW rows below it.  Every multiply and add of the two rays shares one packed instruction (mirt_math2.hpp), the
+// LDS rows of a candidate triangle are read once for both rays, and the per-tile work (candidate masks, direction-box
+// reductions) is spread over twice the pixels.  No supersampling here (k_rt_tile<16, true> keeps that).
+
+struct TestDots2 { f2 den, pu, qv; };
+
+__device__ __forceinline__ TestDots2 test_dots2(const float4 &r0, const float4 &r1, const float4 &r2, const v3p &nd)
+{
+    TestDots2 d;
+    d.den = splat2(r0.x) * nd.x + splat2(r0.y) * nd.y + splat2(r0.z) * nd.z;
+    d.pu = splat2(r1.x) * nd.x + splat2(r1.y) * nd.y + splat2(r1.z) * nd.z;
+    d.qv = splat2(r2.x) * nd.x + splat2(r2.y) * nd.y + splat2(r2.z) * nd.z;
+    return d;
+}
+__device__ __forceinline__ TestDots dots_half(const TestDots2 &d, int h)
+{
+    TestDots r;
+    r.den = h ? d.den.y : d.den.x; r.pu = h ? d.pu.y : d.pu.x; r.qv = h ? d.qv.y : d.qv.x;
+    return r;
+}
+
+// maybe_hit (rt_common.hpp) for both rays: a = s*pu, b = s*qv, D = s*den with s = +-1 carrying den's sign --
+// multiplying by +-1 is exact, so a, b and D have the very bits the scalar filter's xor / fabs produce.
+__device__ __forceinline__ void maybe_hit2(const TestDots2 &d, bool *m0, bool *m1)
+{
+    const f2 s = { __uint_as_float((__float_as_uint(d.den.x) & 0x80000000u) | 0x3f800000u),
+                   __uint_as_float((__float_as_uint(d.den.y) & 0x80000000u) | 0x3f800000u) };
+    const f2 a = d.pu * s, b = d.qv * s, D = d.den * s;
+    const f2 slack = __builtin_elementwise_fma(D, splat2(1.00000095367431640625f), -(a + b));
+    *m0 = fminf(fminf(a.x, b.x), slack.x) >= -2.384185791015625e-07f;
+    *m1 = fminf(fminf(a.y, b.y), slack.y) >= -2.384185791015625e-07f;
+}
+
+template <int TW>
+__device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty, const TileTables &tb)
+{
+    constexpr int TH = 64 / TW;                   // rows per half; the tile is 2*TH rows tall
+    const RtFrame &f = tf.f;
+    const int lane = threadIdx.x & 63, n = f.n;
+    const int x0 = tx * TW, y0 = f.y0 + ty * 2 * TH;
+    const int x = x0 + (lane % TW), ya = y0 + (lane / TW), yb = ya + TH;
+    const bool okx = x < f.W, ok0 = okx && ya < f.y1, ok1 = okx && yb < f.y1;
+    const v3 cam = ld3(f.cam);
+
+    // ---- primary candidates: one lane per triangle tests the tile's pixel rectangle ----
+    bool cand = false;
+    if (lane < n) {
+        TriBinFns t;
+        const float4 a = tb.fns[4 * lane], b = tb.fns[4 * lane + 1], c = tb.fns[4 * lane + 2], d4 = tb.fns[4 * lane + 3];
+        t.n.c0 = a.x; t.n.cu = a.y; t.n.cv = a.z; t.n.m = a.w;
+        t.p.c0 = b.x; t.p.cu = b.y; t.p.cv = b.z; t.p.m = b.w;
+        t.q.c0 = c.x; t.q.cu = c.y; t.q.cv = c.z; t.q.m = c.w;
+        t.s.c0 = d4.x; t.s.cu = d4.y; t.s.cv = d4.z; t.s.m = d4.w;
+        t.nb = tb.cam[3 * lane].w;
+        t.bstate = BOX_NONE; t.bu0 = t.bu1 = t.bv0 = t.bv1 = 0.0f;
+        cand = rect_may_hit(t, (float)x0, (float)min(x0 + TW - 1, f.W - 1), (float)y0, (float)min(y0 + 2 * TH - 1, f.y1 - 1));
+    }
+    const unsigned long long pmask = __ballot(cand);
+    unsigned ntests = 0;                                                     // ray-triangle tests this lane runs
+
+    float bd0 = FLT_MAX, bd1 = FLT_MAX;                                      // Update() reset (:335-339)
+    int bi0 = -1, bi1 = -1;
+    v3 pos0 = V3(0.0f, 0.0f, 0.0f), pos1 = pos0;
+    // d = (x - W/2, y - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
+    const float hw = (float)f.W / 2.0f, hh = (float)f.H / 2.0f;
+    const v3p d = V3P(splat2((float)x - hw), (f2){ (float)ya - hh, (float)yb - hh }, splat2(f.focal));
+    const v3p nd = neg3p(mat3_mul_vecp(f.rot, d));
+    bool any0 = false, any1 = false;                                         // ClosestIntersection's return value
+    {
+        unsigned long long pm = pmask;
+        ntests += (unsigned)__popcll(pm) * ((ok0 ? 1u : 0u) + (ok1 ? 1u : 0u));
+        while (pm) {                                                         // ascending index: the `>=` rule holds
+            const int j = __builtin_ctzll(pm);
+            pm &= pm - 1ull;
+            const float4 r0 = tb.cam[3 * j], r1 = tb.cam[3 * j + 1], r2 = tb.cam[3 * j + 2];
+            const TestDots2 td = test_dots2(r0, r1, r2, nd);
+            bool m0, m1;
+            maybe_hit2(td, &m0, &m1);
+            if (m0 || m1) {
+                v3 hp;
+                float dist;
+                if (m0 && exact_hit_geo(dots_half(td, 0), r0.w, tb.geo + 3 * j, cam, &hp, &dist)) {
+                    any0 = true;
+                    if (bd0 >= dist) { bd0 = dist; bi0 = j; pos0 = hp; }      // :243-247
+                }
+                if (m1 && exact_hit_geo(dots_half(td, 1), r0.w, tb.geo + 3 * j, cam, &hp, &dist)) {
+                    any1 = true;
+                    if (bd1 >= dist) { bd1 = dist; bi1 = j; pos1 = hp; }
+                }
+            }
+        }
+    }
+    const bool hit0 = ok0 && any0, hit1 = ok1 && any1;
+    count_hits(f, (unsigned long long)(__popcll(__ballot(hit0)) + __popcll(__ballot(hit1))));
+
+    v3p avg = splat3(V3(0.0f, 0.0f, 0.0f));
+    if (__any(hit0 || hit1)) {
+        const v3p pos = join3(pos0, pos1);
+        const int s0 = bi0 >= 0 ? bi0 : 0, s1 = bi1 >= 0 ? bi1 : 0;
+        const float4 sa0 = tb.shade[2 * s0], sa1 = tb.shade[2 * s0 + 1], sb0 = tb.shade[2 * s1], sb1 = tb.shade[2 * s1 + 1];
+        const v3p nDir = join3(V3(sa0.x, sa0.y, sa0.z), V3(sb0.x, sb0.y, sb0.z));   // glm::normalize(normal) (:300), per triangle
+        const v3p tcol = join3(V3(sa1.x, sa1.y, sa1.z), V3(sb1.x, sb1.y, sb1.z));
+        v3p result = splat3(V3(0.0f, 0.0f, 0.0f)), result2 = result;
+        for (int k = 0; k < f.nlights; k++) {
+            // DirectLight's term before the shadow test (raytracer.cpp:294-304), both pixels at once
+            const v3 L = ld3(f.lpos[k]);
+            const v3p Lp = splat3(L);
+            const f2 r = distance3p(pos, Lp);
+            const f2 A = { sphere_area(r.x), sphere_area(r.y) };
+            const v3 P = ld3(f.lcol[k]);                                     // lightColor / samples (:296), divided on the host
+            const v3p rd = normalize3p(sub3p(Lp, pos));
+            const v3p B = V3P(splat2(P.x) / A, splat2(P.y) / A, splat2(P.z) / A);
+            const f2 dn = dot3p(rd, nDir);
+            const f2 mx = { (dn.x < 0.0f) ? 0.0f : dn.x, (dn.y < 0.0f) ? 0.0f : dn.y };   // std::max(d, 0.0f)
+            v3p D = scale3p(B, mx);
+            const f2 thr = r * splat2(0.99f);                                // :313
+            const float4 *tab = tb.light + (size_t)3 * n * k;
+            // ---- shadow candidates: direction box of the wave's live rays, one lane per triangle ----
+            const float inf = __builtin_huge_valf();
+            const v3 lo = V3(wave_min_f(fminf(hit0 ? rd.x.x : inf, hit1 ? rd.x.y : inf)),
+                             wave_min_f(fminf(hit0 ? rd.y.x : inf, hit1 ? rd.y.y : inf)),
+                             wave_min_f(fminf(hit0 ? rd.z.x : inf, hit1 ? rd.z.y : inf)));
+            const v3 hi = V3(wave_max_f(fmaxf(hit0 ? rd.x.x : -inf, hit1 ? rd.x.y : -inf)),
+                             wave_max_f(fmaxf(hit0 ? rd.y.x : -inf, hit1 ? rd.y.y : -inf)),
+                             wave_max_f(fmaxf(hit0 ? rd.z.x : -inf, hit1 ? rd.z.y : -inf)));
+            bool sc = false;
+            if (lane < n) sc = box_may_hit(tab[3 * lane], tab[3 * lane + 1], tab[3 * lane + 2], lo, hi);
+            unsigned long long sm = __ballot(sc);
+            ntests += (unsigned)__popcll(sm) * ((hit0 ? 1u : 0u) + (hit1 ? 1u : 0u));
+            bool live0 = hit0, live1 = hit1;
+            while (sm) {
+                const int j = __builtin_ctzll(sm);
+                sm &= sm - 1ull;
+                const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
+                const TestDots2 td = test_dots2(r0, r1, r2, rd);             // negD = rDir (:310, :229)
+                bool m0, m1;
+                maybe_hit2(td, &m0, &m1);
+                m0 = m0 && live0; m1 = m1 && live1;
+                if (m0 || m1) {
+                    v3 hp;
+                    float dist;
+                    if (m0 && exact_hit_geo(dots_half(td, 0), r0.w, tb.geo + 3 * j, L, &hp, &dist) && dist < thr.x) {
+                        live0 = false;                                        // occluded (:313-314); any-hit is exact
+                        D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f;
+                    }
+                    if (m1 && exact_hit_geo(dots_half(td, 1), r0.w, tb.geo + 3 * j, L, &hp, &dist) && dist < thr.y) {
+                        live1 = false;
+                        D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f;
+                    }
+                }
+            }
+            result = add3p(result, D);                                       // :319
+            if ((k + 1) % f.samples == 0) result2 = add3p(result2, result);  // :322, after each light's samples
+        }
+        const v3p Dl = mul3p(result2, tcol);                                 // :325-326
+        const v3p shaded = add3p(avg, mul3p(tcol, add3p(Dl, splat3(ld3(f.indirect)))));   // :584-591 (avgColor += R)
+        avg = join3(hit0 ? half0(shaded) : half0(avg), hit1 ? half1(shaded) : half1(avg));
+    }
+    count_tests(f, ntests);
+    // avgColor /= 1*1 is the identity (:599)
+    if (ok0) {
+        const v3 c = half0(avg);
+        const size_t px = (size_t)ya * f.W + x;
+        if (f.rgb) st3(f.rgb + 3 * px, c);
+        if (f.index) f.index[px] = bi0;
+        if (f.fd) f.fd[px] = bi0 >= 0 ? bd0 - f.focal_plane : 0.0f;            // focalDistances (:248-249)
+        if (x >= 1 && x < f.W - 1 && ya >= 1 && ya < f.H - 1)                // :618-620
+            f.xrgb[(size_t)(ya - f.row_origin) * f.pitch_words + x] = pack_xrgb(c);
+    }
+    if (ok1) {
+        const v3 c = half1(avg);
+        const size_t px = (size_t)yb * f.W + x;
+        if (f.rgb) st3(f.rgb + 3 * px, c);
+        if (f.index) f.index[px] = bi1;
+        if (f.fd) f.fd[px] = bi1 >= 0 ? bd1 - f.focal_plane : 0.0f;
+        if (x >= 1 && x < f.W - 1 && yb >= 1 && yb < f.H - 1)
+            f.xrgb[(size_t)(yb - f.row_origin) * f.pitch_words + x] = pack_xrgb(c);
     }
 }
+
+template <int TW>
+__global__ __launch_bounds__(1024) void k_rt_tile2(const RtTileFrame tf)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_all[];
+    const TileTables tab = tile_tables_build(tf, s_all);
+    const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
+    const int waves = blockDim.x >> 6;
+    for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves)
+        tile_body2<TW>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), tab);
+}
+
+template __global__ void k_rt_tile2<16>(const RtTileFrame);
+template __global__ void k_rt_tile2<32>(const RtTileFrame);
 
 template __global__ void k_rt_tile<8, false>(const RtTileFrame);
 template __global__ void k_rt_tile<16, false>(const RtTileFrame);

@@ -20,7 +20,7 @@ KERNEL_NAMES = ("prep", "bin", "trace", "dof", "raster_setup", "raster_frag", "r
 EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
-    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
+    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats",
 )
 
@@ -66,6 +66,7 @@ def load():
     lib.mirt_cull.argtypes = [_vp, C.c_int, C.POINTER(View), C.c_int, _vp]
     lib.mirt_set_soft_shadows.argtypes = [C.c_int, _vp, C.c_int]
     lib.mirt_set_depth_of_field.argtypes = [C.c_int, C.c_float]
+    lib.mirt_set_frames_in_flight.argtypes = [C.c_int]
     lib.mirt_raytrace.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
     lib.mirt_raytrace_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _vp, C.c_int, _vp, _vp]
@@ -182,6 +183,12 @@ def scene_set_culled(culled):
 def set_depth_of_field(kernel_size, focal_length=0.0):
     """kernel_size x kernel_size blur before the pixels are stored (the reference: 8, FOCAL_LENGTH 1.3 / 1.9); <= 1: off."""
     _check(load().mirt_set_depth_of_field(int(kernel_size), float(focal_length)))
+
+
+def set_frames_in_flight(frames):
+    """1: device calls run in order on one stream; 2: they alternate between two streams (consecutive frames need
+    different output planes)."""
+    _check(load().mirt_set_frames_in_flight(int(frames)))
 
 
 def set_antialiasing(samples):

@@ -95,10 +95,18 @@ MIRT_API int mirt_abi_version(void);
 /* When on, every kernel launch is bracketed by hipEvents on the library stream and mirt_stats.kernel_ms
  * is filled (costs a few microseconds per launch; off by default). */
 MIRT_API int mirt_set_profiling(int on);
-/* Blocks until all work queued on the library stream has finished. */
+/* Blocks until all work queued by the library has finished. */
 MIRT_API int mirt_sync(void);
-/* The library's hipStream_t (as void*), so a caller can order its own work after ours. */
+/* The hipStream_t (as void*) the NEXT *_device call will run on, so a caller can order its own work around ours
+ * (wait for an event before the call, record one after it). */
 MIRT_API void *mirt_stream(void);
+/* How many *_device frames may be in flight at once: 1 (default; calls run in order on one stream) or 2 (calls
+ * alternate between two streams; the next frame is dispatched while the previous one drains, which hides the
+ * dispatch gap between frames).  With 2 the caller must give consecutive frames DIFFERENT output planes -- the
+ * double buffering a render loop that presents one frame while drawing the next already has (the reference's
+ * SDL_UpdateRect after Draw(), raytracer.cpp:653) -- and mirt_sync() before reading them.  Calls whose internal
+ * state is shared between frames (binned mode, the rasteriser, depth of field) are still ordered one after the other. */
+MIRT_API int mirt_set_frames_in_flight(int frames);
 
 /* ---- scene --------------------------------------------------------------------------------------- */
 

@@ -568,3 +568,51 @@ def test_depth_of_field_limits():
     with pytest.raises(mirt.MirtError):
         mirt.set_depth_of_field(65, 1.0)
     mirt.set_depth_of_field(1, 1.0)                                       # <= 1 switches it off
+
+
+# ---- two frames in flight ---------------------------------------------------------------------------------------
+
+def test_two_frames_in_flight(oracle):
+    """mirt_set_frames_in_flight(2): consecutive device calls alternate between two streams.  Frames of two different
+    views rendered back to back into two surfaces must equal the frames rendered one at a time, the statistics must be
+    those of the last call, and calls that share library state (binned mode, rasteriser, depth of field) interleaved
+    with them must still come out right."""
+    tris = mirt.scene_cornell()
+    W, H = 333, 207
+    rot_a, rot_b = oracle.rot_from_yaw(0.0, 1.0), oracle.rot_from_yaw(0.4, 1.0)
+    va = mirt.make_view((0, 0, -2), rot_a, 100.0, W, H)
+    vb = mirt.make_view((0.2, 0.1, -2.3), rot_b, 120.0, W, H)
+    mirt.scene_upload(tris)
+    want_a = mirt.raytrace(va, DEFAULT_LIGHT)
+    want_b = mirt.raytrace(vb, DEFAULT_LIGHT)
+    culled = mirt.cull(tris, va, 3)
+    mirt.scene_upload(tris, culled)
+    want_r = mirt.rasterise(va, DEFAULT_LIGHT)["xrgb"]
+    mirt.scene_upload(tris)
+    sa, sb, sr = _DeviceWords(W, H), _DeviceWords(W, H), _DeviceWords(W, H, 0x99)
+    mirt.set_frames_in_flight(2)
+    try:
+        for i in range(40):
+            mirt.raytrace_device(va, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, sa.ptr, W * 4)
+            mirt.raytrace_device(vb, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, sb.ptr, W * 4)
+        assert mirt.stats()["shadow_rays"] == want_b["stats"]["shadow_rays"]
+        assert np.array_equal(sa.read(), want_a["xrgb"]) and np.array_equal(sb.read(), want_b["xrgb"])
+        # an odd number of calls, then calls that must not overlap their neighbours
+        mirt.raytrace_device(va, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, sa.ptr, W * 4)
+        mirt.raytrace_device(vb, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, sb.ptr, W * 4)
+        mirt.raytrace_device(va, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_BRUTE, 0, H, 0, sa.ptr, W * 4)
+        assert mirt.stats()["shadow_rays"] == want_a["stats"]["shadow_rays"]
+        mirt.scene_upload(tris, culled)
+        mirt.rasterise_device(va, DEFAULT_LIGHT, (0.2, 0.2, 0.2), 0, H, 0, sr.ptr, W * 4)
+        mirt.raytrace_device(vb, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, sb.ptr, W * 4)
+        mirt.rasterise_device(va, DEFAULT_LIGHT, (0.2, 0.2, 0.2), 0, H, 0, sr.ptr, W * 4)
+        assert np.array_equal(sr.read(), want_r)
+        assert np.array_equal(sa.read(), want_a["xrgb"]) and np.array_equal(sb.read(), want_b["xrgb"])
+        got = mirt.raytrace(va, DEFAULT_LIGHT)                               # host-buffer entry point under the same mode
+        assert np.array_equal(got["xrgb"], want_a["xrgb"]) and got["stats"]["shadow_rays"] == want_a["stats"]["shadow_rays"]
+    finally:
+        mirt.set_frames_in_flight(1)
+        for s in (sa, sb, sr):
+            s.free()
+    with pytest.raises(mirt.MirtError):
+        mirt.set_frames_in_flight(3)
