@@ -71,7 +71,9 @@ struct Ctx {
     hipStream_t stream = nullptr;                // the stream of the current call (one of streams[])
     hipStream_t streams[2] = { nullptr, nullptr };
     int in_flight = 1;                           // frames that may be in flight at once (mirt_set_frames_in_flight)
-    uint64_t frame_no = 0;                       // device calls so far; call i runs on streams[i & 1] when in_flight == 2
+    uint64_t frame_no = 0;                       // device calls so far
+    int last_stream = 1;                         // index of the stream the previous call ran on (in_flight == 2)
+    bool last_self_contained = false;            // ... and whether that call may overlap its neighbours
     hipEvent_t ev_chain = nullptr;               // orders a call after the previous one when it must not overlap it
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_used[8] = {};
@@ -197,20 +199,31 @@ hipError_t sync_all()
 
 void k_end(int k) { if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * k + 1], g.stream); }
 
-// Every device call starts here.  With two frames in flight the calls alternate between two streams, so frame i+1 is
-// dispatched while frame i still drains (no dispatch gap, no idle tail).  A call that touches library state shared
-// between frames (origin tables, bins, raster scratch, the depth-of-field planes) is `self_contained == false` and is
-// ordered after the previous call; the tile ray tracer keeps everything in LDS and its hit counters rotate through
-// four buffers, so consecutive frames of it overlap freely.
+// Every device call starts here.  With two frames in flight, calls that are `self_contained` (the tile ray tracer:
+// everything in LDS, hit counters per stream) alternate between two streams, so frame i+1 is dispatched while frame i
+// still drains -- no dispatch gap, no idle tail; frames i and i+2, which a double-buffering caller gives the same
+// planes, stay on one stream.  A call that touches library state shared between frames (origin tables, bins, raster
+// scratch, the depth-of-field planes) is a full barrier: it runs after every earlier call and every later call runs
+// after it.  Runs of such calls stay on one stream (stream order is cheaper than cross-stream events).
 void call_begin(bool self_contained = false)
 {
     if (g.in_flight == 2) {
-        hipStream_t prev = g.stream;
-        g.stream = g.streams[g.frame_no & 1];
-        if (!self_contained && prev != g.stream) {
-            (void)hipEventRecord(g.ev_chain, prev);
-            (void)hipStreamWaitEvent(g.stream, g.ev_chain, 0);
+        const int last = g.last_stream;
+        if (self_contained) {
+            g.stream = g.streams[last ^ 1];
+            if (!g.last_self_contained) {                        // first frame after a barrier call: order it after that call
+                (void)hipEventRecord(g.ev_chain, g.streams[last]);
+                (void)hipStreamWaitEvent(g.stream, g.ev_chain, 0);
+            }
+            g.last_stream = last ^ 1;
+        } else {
+            g.stream = g.streams[last];
+            if (g.last_self_contained) {                         // the frame before the last one may still run on the other stream
+                (void)hipEventRecord(g.ev_chain, g.streams[last ^ 1]);
+                (void)hipStreamWaitEvent(g.stream, g.ev_chain, 0);
+            }
         }
+        g.last_self_contained = self_contained;
     }
     g.frame_no++;
     memset(&g.stats, 0, sizeof g.stats);
@@ -682,6 +695,8 @@ extern "C" int mirt_init(int device)
     g.stream = g.streams[0];
     g.in_flight = 1;
     g.frame_no = 0;
+    g.last_stream = 1;
+    g.last_self_contained = false;
     HIP_TRY(hipEventCreateWithFlags(&g.ev_chain, hipEventDisableTiming));
     for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev[i]));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
@@ -731,12 +746,7 @@ extern "C" int mirt_sync(void)
     return MIRT_OK;
 }
 
-// The stream the NEXT device call will run on (with two frames in flight the calls alternate between two streams).
-extern "C" void *mirt_stream(void)
-{
-    if (!g.init) return nullptr;
-    return (void *)(g.in_flight == 2 ? g.streams[g.frame_no & 1] : g.stream);
-}
+extern "C" void *mirt_stream(void) { return g.init ? (void *)g.stream : nullptr; }
 
 extern "C" int mirt_set_frames_in_flight(int frames)
 {
@@ -745,7 +755,9 @@ extern "C" int mirt_set_frames_in_flight(int frames)
     if (frames < 1 || frames > 2) return fail(MIRT_ERR_INVALID_ARGUMENT, "frames in flight must be 1 or 2, not %d", frames);
     HIP_TRY(sync_all());
     g.in_flight = frames;
-    if (frames == 1) g.stream = g.streams[0];
+    g.stream = g.streams[0];
+    g.last_stream = 1;                       // the first overlapping frame takes streams[0]
+    g.last_self_contained = false;
     return MIRT_OK;
 }
 

@@ -97,8 +97,9 @@ MIRT_API int mirt_abi_version(void);
 MIRT_API int mirt_set_profiling(int on);
 /* Blocks until all work queued by the library has finished. */
 MIRT_API int mirt_sync(void);
-/* The hipStream_t (as void*) the NEXT *_device call will run on, so a caller can order its own work around ours
- * (wait for an event before the call, record one after it). */
+/* The library's hipStream_t (as void*), so a caller can order its own work around ours (wait for an event before a
+ * call, record one after it).  With two frames in flight (below) it is the stream of the most recent call only:
+ * order with mirt_sync() instead. */
 MIRT_API void *mirt_stream(void);
 /* How many *_device frames may be in flight at once: 1 (default; calls run in order on one stream) or 2 (calls
  * alternate between two streams; the next frame is dispatched while the previous one drains, which hides the
