@@ -26,7 +26,9 @@ struct RtTileFrame {
     BinFrameDesc cam;
     int tiles_x, tiles_y;
     unsigned long long *clear_hits;
+    float4 *tables;
 };
+__global__ void k_tile_tables(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
 template <int TW> __global__ void k_rt_tile2(const RtTileFrame);
 template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
@@ -91,6 +93,7 @@ struct Ctx {
     unsigned long long *d_hits2[4] = { nullptr, nullptr, nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
     bool hits_clean[4] = { false, false, false, false };   // buffer is all zero (the tile kernel clears the one two frames ahead itself)
     int hits_cur = 0;
+    float4 *d_tile_tab[2] = { nullptr, nullptr };   // per-stream tables of the tile ray tracer (k_tile_tables)
     int hits_tog[2] = { 0, 0 };
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
@@ -420,6 +423,15 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         g.pending_counted = true;
         tf.clear_hits = g.d_hits2[g.hits_cur ^ 2];       // zeroed by this launch for the next frame on this stream: no memset node per frame
         g.hits_clean[g.hits_cur ^ 2] = true;
+        // Tables: built once per frame by k_tile_tables when the frame has enough workgroups to make rebuilding them in
+        // each one the larger cost; small frames are bound by the launch rate and keep the single launch.
+        static const int tab_blocks = [] { const char *e = getenv("MIRT_TILE_TABLE_BLOCKS"); return e ? atoi(e) : 1024; }();
+        tf.tables = (int)blocks >= tab_blocks ? g.d_tile_tab[g.hits_cur & 1] : nullptr;   // one table buffer per stream
+        if (tf.tables) {
+            k_begin(MIRT_K_PREP);
+            hipLaunchKernelGGL(k_tile_tables, dim3(1), dim3(64), 0, g.stream, tf);
+            k_end(MIRT_K_PREP);
+        }
         k_begin(MIRT_K_TRACE);
         if (f.aa > 1) hipLaunchKernelGGL((k_rt_tile<16, true>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
         else if (two && tw == 16) hipLaunchKernelGGL((k_rt_tile2<16>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
@@ -707,6 +719,7 @@ extern "C" int mirt_init(int device)
         HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
         g.hits_clean[i] = true;
     }
+    for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_tile_tab[i]), sizeof(float4) * 64 * (12 + 3 * MIRT_MAX_LIGHTS)));
     g.d_hits = g.d_hits2[0];
     g.device = device;
     g.init = true;
@@ -719,7 +732,7 @@ extern "C" void mirt_shutdown(void)
     (void)hipSetDevice(g.device);
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
-                     (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
+                     (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
                      (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries,
                      (void *)g.d_dof_rgb, (void *)g.d_dof_fd, (void *)g.d_dof_xrgb, (void *)g.d_dof_index, (void *)g.d_dof_zinv })
         if (p) (void)hipFree(p);

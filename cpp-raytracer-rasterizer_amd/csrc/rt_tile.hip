@@ -23,22 +23,35 @@ struct RtTileFrame {
     RtFrame f;
     BinFrameDesc cam;        // camera ray family (P0, Pu, Pv, dmax); bins are not used, only the edge functions
     int tiles_x, tiles_y;    // tiles in the band
-    unsigned long long *clear_hits;   // the OTHER hit-counter buffer: zeroed here for the next frame (saves a memset launch)
+    unsigned long long *clear_hits;   // the OTHER hit-counter buffer of this stream: zeroed by k_tile_tables for the next frame
+    float4 *tables;                   // tile_table_rows() float4, built by k_tile_tables, copied into LDS by every workgroup
 };
 
 
+// 64-lane min / max without LDS traffic: four row_shr steps fold each row of 16 lanes into its lane 15, row_bcast:15
+// and row_bcast:31 carry the row results into lane 63, v_readlane makes the result wave-uniform (an SGPR).  Lanes a
+// step has no source for are skipped by the hardware and keep their value.  Written as v_min_f32_dpp / v_max_f32_dpp
+// directly (the compiler keeps a separate v_mov_b32_dpp per step otherwise); the s_nop 1 are the two wait states a
+// DPP read needs after a VALU write of the same register.
+#define MIRT_DPP_REDUCE(OP)                                                                      \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"             \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"             \
+        "s_nop 1" : "+v"(v))
 __device__ __forceinline__ float wave_min_f(float v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d));
-    return v;
+    MIRT_DPP_REDUCE("v_min_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max_f(float v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    return v;
+    MIRT_DPP_REDUCE("v_max_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+#undef MIRT_DPP_REDUCE
 
 // interval of g . x for x in the box [lo, hi]
 __device__ __forceinline__ void dot_range(float gx, float gy, float gz, v3 lo, v3 hi, float *rlo, float *rhi)
@@ -204,48 +217,72 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
 
-// LDS tables of a workgroup: origin rows of the camera and of every light position, geometry, the camera-frame edge
-// functions and the shading constants of every triangle.
-struct TileTables { float4 *cam, *geo, *fns, *shade, *light; };
+// Per-frame tables of the tile kernels: origin rows of the camera and of every light position, geometry, the
+// camera-frame edge functions and the shading constants of every triangle -- (12 + 3*nlights) float4 per triangle.
+// k_tile_tables builds them once per frame (one lane per triangle) into tf.tables; every workgroup of the tile
+// kernels copies them into LDS.  (Building them in each of the ~4000 workgroups cost about a tenth of the frame's
+// VALU issue slots.)
+struct TileTables { const float4 *cam, *geo, *fns, *shade, *light; };
 
-__device__ __forceinline__ TileTables tile_tables_build(const RtTileFrame &tf, float4 *s_all)
+__host__ __device__ __forceinline__ int tile_table_rows(int n, int nlights) { return n * (12 + 3 * nlights); }
+
+// The rows of triangle t, written to tables laid out as described above (global memory or LDS).
+__device__ __forceinline__ void tile_table_rows_of(const RtTileFrame &tf, int t, float4 *base)
 {
     const RtFrame &f = tf.f;
     const int n = f.n;
-    TileTables tb;
-    tb.cam = s_all;                       // 3 rows per triangle
-    tb.geo = tb.cam + 3 * n;               // 3
-    tb.fns = tb.geo + 3 * n;               // 4: the camera-frame edge functions n, p, q, s
-    tb.shade = tb.fns + 4 * n;             // 2: {normalize(normal), -}, {color, -}
-    tb.light = tb.shade + 2 * n;           // nlights x 3 rows per triangle
-    float4 *s_cam = tb.cam, *s_geo = tb.geo, *s_fns = tb.fns, *s_shade = tb.shade, *s_light = tb.light;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        const float *t15 = f.tris15 + (size_t)15 * t;
-        const OriginRow r = make_origin_row(t15, ld3(f.cam));
-        s_cam[3 * t] = r.r0; s_cam[3 * t + 1] = r.r1; s_cam[3 * t + 2] = r.r2;
-        const v3 v0 = ld3(t15), e1 = sub3(ld3(t15 + 3), v0), e2 = sub3(ld3(t15 + 6), v0);       // :216-217
-        s_geo[3 * t] = make_float4(v0.x, v0.y, v0.z, e1.x);
-        s_geo[3 * t + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-        s_geo[3 * t + 2] = make_float4(e2.z, 0.0f, 0.0f, 0.0f);
-        const TriBinFns b = make_bin_fns(r, tf.cam);
-        s_fns[4 * t] = make_float4(b.n.c0, b.n.cu, b.n.cv, b.n.m);
-        s_fns[4 * t + 1] = make_float4(b.p.c0, b.p.cu, b.p.cv, b.p.m);
-        s_fns[4 * t + 2] = make_float4(b.q.c0, b.q.cu, b.q.cv, b.q.m);
-        s_fns[4 * t + 3] = make_float4(b.s.c0, b.s.cu, b.s.cv, b.s.m);
-        const v3 nd = normalize3(ld3(t15 + 9));                              // :300
-        s_shade[2 * t] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-        s_shade[2 * t + 1] = make_float4(t15[12], t15[13], t15[14], 0.0f);
-        for (int k = 0; k < f.nlights; k++) {
-            const OriginRow rl = make_origin_row(t15, ld3(f.lpos[k]));
-            float4 *dst = s_light + 3 * ((size_t)k * n + t);
-            dst[0] = rl.r0; dst[1] = rl.r1; dst[2] = rl.r2;
-        }
+    float4 *s_cam = base;                        // 3 rows per triangle
+    float4 *s_geo = s_cam + 3 * n;               // 3
+    float4 *s_fns = s_geo + 3 * n;               // 4: the camera-frame edge functions n, p, q, s
+    float4 *s_shade = s_fns + 4 * n;             // 2: {normalize(normal), -}, {color, -}
+    float4 *s_light = s_shade + 2 * n;           // nlights x 3 rows per triangle
+    const float *t15 = f.tris15 + (size_t)15 * t;
+    const OriginRow r = make_origin_row(t15, ld3(f.cam));
+    s_cam[3 * t] = r.r0; s_cam[3 * t + 1] = r.r1; s_cam[3 * t + 2] = r.r2;
+    const v3 v0 = ld3(t15), e1 = sub3(ld3(t15 + 3), v0), e2 = sub3(ld3(t15 + 6), v0);       // :216-217
+    s_geo[3 * t] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    s_geo[3 * t + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    s_geo[3 * t + 2] = make_float4(e2.z, 0.0f, 0.0f, 0.0f);
+    const TriBinFns b = make_bin_fns(r, tf.cam);
+    s_fns[4 * t] = make_float4(b.n.c0, b.n.cu, b.n.cv, b.n.m);
+    s_fns[4 * t + 1] = make_float4(b.p.c0, b.p.cu, b.p.cv, b.p.m);
+    s_fns[4 * t + 2] = make_float4(b.q.c0, b.q.cu, b.q.cv, b.q.m);
+    s_fns[4 * t + 3] = make_float4(b.s.c0, b.s.cu, b.s.cv, b.s.m);
+    const v3 nd = normalize3(ld3(t15 + 9));                                  // :300
+    s_shade[2 * t] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+    s_shade[2 * t + 1] = make_float4(t15[12], t15[13], t15[14], 0.0f);
+    for (int k = 0; k < f.nlights; k++) {
+        const OriginRow rl = make_origin_row(t15, ld3(f.lpos[k]));
+        float4 *dst = s_light + 3 * ((size_t)k * n + t);
+        dst[0] = rl.r0; dst[1] = rl.r1; dst[2] = rl.r2;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tile_tables(const RtTileFrame tf)
+{
+    for (int i = threadIdx.x; i < HIT_SHARDS * HIT_SHARD_STRIDE; i += 64) tf.clear_hits[i] = 0ull;   // counters of the next frame on this stream
+    if ((int)threadIdx.x < tf.f.n) tile_table_rows_of(tf, threadIdx.x, tf.tables);
+}
+
+// tf.tables != nullptr: copy the tables k_tile_tables built; nullptr (small frames: a second launch would cost more
+// than it saves): build them here, and let workgroup 0 clear the next frame's hit counters.
+__device__ __forceinline__ TileTables tile_tables_load(const RtTileFrame &tf, float4 *s_all)
+{
+    const int n = tf.f.n, rows = tile_table_rows(n, tf.f.nlights);
+    if (tf.tables) {
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) s_all[i] = tf.tables[i];
+    } else {
+        for (int t = threadIdx.x; t < n; t += blockDim.x) tile_table_rows_of(tf, t, s_all);
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < HIT_SHARDS * HIT_SHARD_STRIDE; i += blockDim.x) tf.clear_hits[i] = 0ull;
     }
     __syncthreads();
-
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < HIT_SHARDS * HIT_SHARD_STRIDE; i += blockDim.x) tf.clear_hits[i] = 0ull;
-
+    TileTables tb;
+    tb.cam = s_all;
+    tb.geo = tb.cam + 3 * n;
+    tb.fns = tb.geo + 3 * n;
+    tb.shade = tb.fns + 4 * n;
+    tb.light = tb.shade + 2 * n;
     return tb;
 }
 
@@ -253,7 +290,7 @@ template <int TW, bool AA>
 __global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
-    const TileTables tab = tile_tables_build(tf, s_all);
+    const TileTables tab = tile_tables_load(tf, s_all);
     const float4 *s_cam = tab.cam, *s_geo = tab.geo, *s_fns = tab.fns, *s_shade = tab.shade, *s_light = tab.light;
     // one tile per wave when the grid covers the frame (the default, see mirt_capi.hip); a smaller grid strides
     const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
@@ -448,7 +485,7 @@ template <int TW>
 __global__ __launch_bounds__(1024) void k_rt_tile2(const RtTileFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
-    const TileTables tab = tile_tables_build(tf, s_all);
+    const TileTables tab = tile_tables_load(tf, s_all);
     const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
     const int waves = blockDim.x >> 6;
     for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves)
