@@ -280,7 +280,7 @@ def main():
                            "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
             })
             kt = kernel_ms.get("trace", 0.0)
-            kname = {mirt.RT_BRUTE: "k_rt_tile" if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
+            kname = {mirt.RT_BRUTE: ("k_rt_tile<" if aa > 1 else "k_rt_tile2") if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
                      mirt.RT_BINNED: "k_rt_binned"}[st["mode_used"]]
             # algorithmic flops per launch = ray-triangle tests the launch executed x 60 flop per test as written in
             # the reference (brute force: rays x triangles; binned: candidates actually tested, counted in-kernel)

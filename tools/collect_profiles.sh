@@ -3,7 +3,7 @@
 # bench lines with cpu_baseline, rocprofv3 kernel stats, and the HBM-traffic PMC passes.  Results land in
 # gpurun_out/; tools/store_profiles.py copies the summaries into profiles/ afterwards (in the build container).
 set -uo pipefail
-for w in cornell1080 soup100k raster4k cornell500 cornell1080soft16; do
+for w in cornell1080 soup100k raster4k cornell500 cornell1080soft16 cornell1080aa3 cornell1080dof8 raster4kdof8; do
   python bench.py --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err; echo "bench $w rc=$?"
 done
 python bench.py --workload soup1m8k --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_soup1m8k.json 2>/dev/null; echo "bench soup1m8k rc=$?"
@@ -13,4 +13,7 @@ for t in cornell1080 soup100k raster4k; do
   tools/pmc_hbm.sh $t --workload $t --steps 10 --warmup 2 > /dev/null 2>&1
   python tools/pmc_summary.py gpurun_out/pmc_$t > gpurun_out/pmc_$t/summary.json
 done
+tools/pmc_valu.sh cornell1080 --workload cornell1080 --steps 50 --warmup 5 > gpurun_out/pmcv_cornell1080.txt 2>&1
+tools/pmc_valu.sh raster4kdof8 --workload raster4kdof8 --steps 20 --warmup 2 > gpurun_out/pmcv_raster4kdof8.txt 2>&1
+tools/ubench > gpurun_out/ubench.txt 2>&1
 echo done

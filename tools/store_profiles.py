@@ -21,4 +21,12 @@ for t in ("cornell1080", "soup100k", "raster4k"):
         traffic["workloads"][t] = json.load(open(s))
 if traffic["workloads"]:
     json.dump(traffic, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
+for t in ("cornell1080", "raster4kdof8"):
+    src = "gpurun_out/pmcv_%s.txt" % t
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        # keep our kernels' lines only (kernel-trace stats + the two issue-side PMC passes)
+        keep = [l for l in open(src) if ("mirt::" in l or l.startswith('"Name"') or l.startswith("trace rc") or l.startswith("pmc"))]
+        open("profiles/%s_pmc_issue_%s.txt" % (tag, t), "w").writelines(keep)
+if os.path.exists("gpurun_out/ubench.txt") and os.path.getsize("gpurun_out/ubench.txt") > 0:
+    shutil.copy("gpurun_out/ubench.txt", "profiles/%s_ubench_valu_lds.txt" % tag)
 print(sorted(os.listdir("profiles")))
