@@ -1,6 +1,7 @@
 // mirt_capi.hip -- the C-ABI of include/mirt.h on top of the HIP kernels.  Owns the device scene, the
 // library stream, staging buffers and the per-call statistics.  No CPU fallback: without a gfx950 device
 // every compute entry point returns MIRT_ERR_NO_DEVICE.
+#include "bin_sort.hpp"
 #include "dof.hpp"
 #include "rt_common.hpp"
 #include "raster_common.hpp"
@@ -31,7 +32,8 @@ struct RtTileFrame {
 __global__ void k_tile_tables(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
 template <int TW> __global__ void k_rt_tile2(const RtTileFrame);
-template <bool FILL> __global__ void k_bin(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
+__global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
+__global__ void k_bin_offsets(const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *);
 struct RtBinnedFrame {
     RtFrame f;
     BinSet bins;
@@ -111,8 +113,11 @@ struct Ctx {
 
     // binned ray tracing: frame descriptors, per-bin offsets / cursors, candidate entries
     BinFrameDesc *d_frames = nullptr;
-    uint32_t *d_bin_off = nullptr, *d_bin_fill = nullptr, *d_bin_sums = nullptr, *d_bin_counters = nullptr;
-    uint32_t *d_entries = nullptr;
+    uint32_t *d_bin_off = nullptr, *d_bin_counters = nullptr;
+    uint32_t *d_entries = nullptr;               // triangle ids ordered by bin (the sorted pair values)
+    uint32_t *d_pair_keys = nullptr, *d_pair_vals = nullptr, *d_sorted_keys = nullptr;   // unsorted pairs, sorted bin ids
+    void *d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
     uint32_t cap_bins = 0, cap_entries = 0;
     uint64_t bin_key = 0;
     uint32_t bin_entries = 0;                    // candidate-list entries of the current binning
@@ -362,7 +367,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
 
     // ---- mode: brute force for small scenes, binned otherwise; unsafe operands always render exact brute ----
     static const int auto_threshold = [] { const char *e = getenv("MIRT_BIN_THRESHOLD"); return e ? atoi(e) : 512; }();
-    static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 1; return (p == 2) ? 2 : 1; }();
+    // rays per lane of the brute-force / LDS-resident kernels: 2 = packed FP32 filter (188 -> 163 ms on the 100 k soup)
+    static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 2; return (p == 1) ? 1 : 2; }();
     bool binned = (mode == MIRT_RT_BINNED) ||
                   (mode == MIRT_RT_AUTO && g.n >= auto_threshold && (long long)view->width * (y1 - y0) > 4096);
     if (!safe) binned = false;
@@ -529,29 +535,35 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     if (nbins + 1 > g.cap_bins) {
         const size_t cap = (size_t)nbins + 1;
         if ((rc = dev_realloc(&g.d_bin_off, cap))) { g.cap_bins = 0; return rc; }
-        if ((rc = dev_realloc(&g.d_bin_fill, cap))) { g.cap_bins = 0; return rc; }
-        if ((rc = dev_realloc(&g.d_bin_sums, cap / SCAN_ITEMS + 2))) { g.cap_bins = 0; return rc; }
         g.cap_bins = (uint32_t)cap;
         g.bin_key_valid = false;
     }
     if (!g.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_frames), sizeof(BinFrameDesc) * MAX_BIN_FRAMES));
-    if (!g.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_bin_counters), 16)); HIP_TRY(hipMemset(g.d_bin_counters, 0, 16)); }
-    if (!g.d_entries) {
-        const size_t cap = (size_t)1 << 20;
-        if ((rc = dev_realloc(&g.d_entries, cap))) return rc;
+    if (!g.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_bin_counters), 64)); HIP_TRY(hipMemset(g.d_bin_counters, 0, 64)); }
+    int key_bits = 1;
+    while ((1u << key_bits) < nbins && key_bits < 32) key_bits++;
+    auto ensure_pairs = [&](size_t cap) -> int {           // pair list, its sorted copy and the sort's scratch, all for `cap` pairs
+        int r;
+        if ((r = dev_realloc(&g.d_entries, cap)) || (r = dev_realloc(&g.d_pair_keys, cap)) || (r = dev_realloc(&g.d_pair_vals, cap)) ||
+            (r = dev_realloc(&g.d_sorted_keys, cap))) { g.cap_entries = 0; return r; }
+        const size_t need = bin_sort_temp_bytes((uint32_t)cap, 32);
+        if (need == 0) return fail(MIRT_ERR_HIP, "radix sort: cannot size its temporary storage for %zu pairs", cap);
+        if (need > g.sort_temp_bytes) {
+            if (g.d_sort_temp) (void)hipFree(g.d_sort_temp);
+            g.d_sort_temp = nullptr; g.sort_temp_bytes = 0;
+            if (hipMalloc(&g.d_sort_temp, need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "radix sort scratch (%zu bytes)", need);
+            g.sort_temp_bytes = need;
+        }
         g.cap_entries = (uint32_t)cap;
+        return MIRT_OK;
+    };
+    if (!g.d_entries || !g.cap_entries) {
+        if ((rc = ensure_pairs((size_t)1 << 20))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(g.d_frames, frames, sizeof(BinFrameDesc) * nframes, hipMemcpyHostToDevice, g.stream));
 
-    BinGridInfo gi;
-    const int L0 = BIN_COARSE * BIN_COARSE;
-    gi.cam_cells_x = (uint32_t)((frames[0].nbu + L0 - 1) / L0);
-    gi.cam_cell_y0 = (uint32_t)(frames[0].j0 / L0);
-    gi.cam_cells = gi.cam_cells_x * (uint32_t)((frames[0].j1 + L0 - 1) / L0 - frames[0].j0 / L0);
-    gi.face_cells_x = (uint32_t)(cube_bins / L0);
-    gi.cells_per_tri = gi.cam_cells + (uint32_t)(nframes - 1) * gi.face_cells_x * gi.face_cells_x;
-    const size_t bin_threads = (size_t)g.n * gi.cells_per_tri;
-    const unsigned bin_blocks = (unsigned)((bin_threads + 255) / 256);
+    // persistent workgroups over the (256-triangle chunk, frame) work items: 3 per CU (52 KiB of LDS each)
+    const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + 255) / 256) * nframes, (long long)g.cu_count * 3));
 
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
     {
@@ -561,45 +573,40 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
 
     BinSet bs;
     bs.frames = g.d_frames; bs.nframes = nframes; bs.nbins = nbins;
-    bs.bin_off = g.d_bin_off; bs.bin_fill = g.d_bin_fill; bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
+    bs.bin_off = g.d_bin_off; bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
     bs.counters = g.d_bin_counters;
     k_begin(MIRT_K_BIN);
-    HIP_TRY(hipMemsetAsync(g.d_bin_off, 0, sizeof(uint32_t) * ((size_t)nbins + 1), g.stream));
-    HIP_TRY(hipMemsetAsync(g.d_bin_fill, 0, sizeof(uint32_t) * (size_t)nbins, g.stream));
-    hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_tris, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
-    enqueue_exclusive_scan(g.d_bin_off, (int)nbins, g.d_bin_sums, g.d_bin_counters, g.stream);
-    // The entry table is sized from a count only the device knows; it is read back (4 bytes + one sync) only
-    // when the inputs that determine it changed since the last frame.
-    if (!g.bin_key_valid || g.bin_key != key) {
+    // The pair list is sized from a count only the device knows; it is read back (4 bytes + one sync) only when the
+    // inputs that determine it changed since the last frame, and the pass is repeated if the list was too small.
+    const bool fresh = !g.bin_key_valid || g.bin_key != key;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        BinPairs pairs = { g.d_pair_keys, g.d_pair_vals, g.cap_entries };
+        HIP_TRY(hipMemsetAsync(g.d_bin_counters, 0, 4, g.stream));
+        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(256), 0, g.stream, g.d_tris, g.d_cam_tab, g.d_light_tab, g.n, bs, pairs);
+        if (!fresh) break;
         uint32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, g.d_bin_counters, 4, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        if (total > g.cap_entries) {
-            const size_t cap = (size_t)total + total / 8 + 4096;
-            if ((rc = dev_realloc(&g.d_entries, cap))) { g.cap_entries = 0; return rc; }
-            g.cap_entries = (uint32_t)cap;
-            bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
-        }
         g.bin_entries = total;
-#ifdef MIRT_BIN_STATS
-        {
-            uint32_t c[4];
-            (void)hipMemcpy(c, g.d_bin_counters, 16, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[mirt bin stats] tris=%d frames=%d cells/tri=%u  L0 passes=%u  L1 passes=%u  entries=%u  bins=%u\n",
-                    g.n, nframes, gi.cells_per_tri, c[2], c[3], total, nbins);
-            for (int fi = 0; fi < nframes; fi++) {
-                uint32_t a = 0, b = 0;
-                const uint32_t end = (fi + 1 < nframes) ? frames[fi + 1].base : nbins;
-                (void)hipMemcpy(&a, g.d_bin_off + frames[fi].base, 4, hipMemcpyDeviceToHost);
-                (void)hipMemcpy(&b, g.d_bin_off + end, 4, hipMemcpyDeviceToHost);
-                fprintf(stderr, "[mirt bin stats]   frame %d: %u entries\n", fi, b - a);
-            }
-        }
-#endif
-        g.bin_key = key;
-        g.bin_key_valid = true;
+        if (total <= g.cap_entries) break;
+        if (attempt == 1) return fail(MIRT_ERR_HIP, "binning produced %u pairs twice with room for %u", total, g.cap_entries);
+        if ((rc = ensure_pairs((size_t)total + total / 8 + 4096))) return rc;
+        bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
     }
-    hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, g.stream, g.d_tris, g.d_cam_tab, g.d_light_tab, g.n, bs, gi);
+#ifdef MIRT_BIN_STATS
+    if (fresh) {
+        uint32_t c[16];
+        (void)hipMemcpy(c, g.d_bin_counters, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mirt bin stats] flattened tests=%u max per work item=%u direct items=%u | huge: box valid=%u no box=%u (camera frame %u)\n", c[8], c[9], c[10], c[11], c[12], c[14]);
+        fprintf(stderr, "[mirt bin stats] tris=%d frames=%d  pairs=%u  bins=%u | large items walked=%u level-1 rounds=%u level-2 steps=%u pairs=%u max steps/item=%u items>100 steps=%u\n",
+                g.n, nframes, g.bin_entries, nbins, c[2], c[3], c[4], c[5], c[6], c[7]);
+        (void)hipMemset(g.d_bin_counters + 2, 0, 56);
+    }
+#endif
+    g.bin_key = key;
+    g.bin_key_valid = true;
+    HIP_TRY(bin_sort_pairs(g.d_sort_temp, g.sort_temp_bytes, g.d_pair_keys, g.d_sorted_keys, g.d_pair_vals, g.d_entries, g.bin_entries, key_bits, g.stream));
+    hipLaunchKernelGGL(k_bin_offsets, dim3((nbins + 1 + 255) / 256), dim3(256), 0, g.stream, g.d_sorted_keys, g.d_bin_counters, g.cap_entries, nbins, g.d_bin_off);
     k_end(MIRT_K_BIN);
 
     bf.f = f;
@@ -733,7 +740,7 @@ extern "C" void mirt_shutdown(void)
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
                      (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
-                     (void *)g.d_bin_fill, (void *)g.d_bin_sums, (void *)g.d_bin_counters, (void *)g.d_entries,
+                     (void *)g.d_bin_counters, (void *)g.d_entries, (void *)g.d_pair_keys, (void *)g.d_pair_vals, (void *)g.d_sorted_keys, g.d_sort_temp,
                      (void *)g.d_dof_rgb, (void *)g.d_dof_fd, (void *)g.d_dof_xrgb, (void *)g.d_dof_index, (void *)g.d_dof_zinv })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster);

@@ -6,15 +6,28 @@
 
 namespace mirt {
 
-// ---- hierarchical binning: three levels of the same conservative rectangle test, one kernel -----------
+// ---- binning: (bin, triangle) pairs in one pass, ordered by a radix sort ----------------------------------------
 //
-//   level 0  one THREAD per (triangle, frame, 64x64-bin cell): one rectangle test
-//   level 1  the wave then takes its surviving lanes one at a time (ballot loop, item broadcast with v_readlane):
-//            lane = one of the cell's 8x8 coarse cells (8x8 bins each)
-//   level 2  for every surviving coarse cell: lane = one of its 64 bins -> count (pass 1) or fill (pass 2)
-// All 64 lanes always work on the same item, so triangle size does not cause divergence, and no work queue
-// (hence no contended queue counter) is needed.  COUNT and FILL run the identical tests, so the fill pass
-// finds exactly the slots the count pass reserved.
+// k_bin_pairs: persistent workgroups; a work item is (256 consecutive triangles, one frame), one thread per triangle.
+// The thread sets up the folded edge functions and the (u,v) box of its triangle in that frame once.  Then
+//   * boxes of at most 32 x 32 bins (everything in a large mesh): the (triangle, bin-of-its-box) tests of the whole
+//     workgroup are FLATTENED -- an exclusive prefix of the box sizes in LDS, and thread t of each round takes test
+//     number t (binary search for its triangle, constants from LDS) -- so a triangle that covers 300 bins and one that
+//     covers 2 cost what they should, and every lane works.  (First version: one wave per such triangle walking 64 bins
+//     at a time with 5 of 64 lanes passing: 250 us.)
+//   * larger boxes or none (walls, triangles crossing a cube face's plane): the WAVE takes such lanes one at a time
+//     (ballot loop, item broadcast with v_readlane) through three levels of the same conservative rectangle test --
+//     lane = 64x64-bin cell, lane = 8x8-bin coarse cell, lane = bin -- after the LANE has tried level 0 itself, which
+//     already discards most of them.
+// Passing (bin, triangle) pairs are appended to an LDS buffer (one LDS atomic per wave and round) and leave through
+// coalesced copies with ONE atomic on the global list's length per flush.
+// bin_sort.hip then orders the pairs by bin (rocPRIM radix sort over the bits a bin id needs) and k_bin_offsets finds
+// every bin's range by binary search: `entries` = the sorted triangle ids, `bin_off` as before.
+//
+// Why not count / scan / fill with one atomic per pair (the first version): a CU retires one global atomic per ~24
+// cycles (tools/sortbench.hip: 25 G atomics/s chip-wide, returning or not), the fill pass's atomic -> dependent store
+// chain made it latency-bound (174 + 365 us measured for the 1.8 M pairs of the 100 k soup), and atomics on ONE
+// address (a list length bumped per workgroup) retire one per ~7 ns.  Sorting the same pairs takes ~80 us.
 //
 // The rectangle test of rt_binned.hpp (rect_may_hit) is evaluated here in "folded" form.  The sign of e1e2b
 // decides which of its two branches can hold (t >= 0 needs sign(e1e2d) == sign(e1e2b)), so the four functions
@@ -26,134 +39,326 @@ namespace mirt {
 constexpr int BIN_L0 = BIN_COARSE * BIN_COARSE;       // 64 bins per level-0 cell side
 
 struct BinItem {
-    float A1[4], A2[4], Bu[4], Bv[4];     // level-1 (K = 8) and level-2 (K = 1) constants, per-bin slopes
-    float lou, hiu, lov, hiv;             // box as bin-index ranges: cell [I, I+K) overlaps iff I+K >= lou && I <= hiu
+    float A0[4], A1[4], A2[4], Bu[4], Bv[4];   // level-0 (K = 64), level-1 (K = 8) and level-2 (K = 1) constants, per-bin slopes
+    float lou, hiu, lov, hiv;                  // box as bin-index ranges: cell [I, I+K) overlaps iff I+K >= lou && I <= hiu
 };
 
 __device__ __forceinline__ float bcastf(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
 
 __device__ __forceinline__ float corner(float s, float lo, float hi) { return fmaxf(s * lo, s * hi); }
 
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
-                                             const OriginRow *__restrict__ light_tab, int n, BinSet bs, BinGridInfo gi)
+// the cell of K x K bins that starts at bin (I, J): may it hold an accepted ray?  A = the item's constants for K
+__device__ __forceinline__ bool cell_may_hit(const BinItem &u, const float (&A)[4], float I, float J, float K)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t tri = id / gi.cells_per_tri;
-    // which (frame, level-0 cell) this thread owns: frame 0 has cam_cells cells, every cube face face_cells_x^2
-    const uint32_t c = id - tri * gi.cells_per_tri;
-    uint32_t frame, cx, cy;
-    if (c < gi.cam_cells) { frame = 0; cx = c % gi.cam_cells_x; cy = gi.cam_cell_y0 + c / gi.cam_cells_x; }
-    else {
-        const uint32_t per_face = gi.face_cells_x * gi.face_cells_x, cc = c - gi.cam_cells;
-        frame = 1 + cc / per_face;
-        const uint32_t within = cc - (frame - 1) * per_face;
-        cx = within % gi.face_cells_x; cy = within / gi.face_cells_x;
-    }
-    bool pass0 = false;
-    BinItem it;
-    memset(&it, 0, sizeof it);
-    if (tri < (uint32_t)n) {
-        const BinFrameDesc &fr = bs.frames[frame];
-        const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
-        TriBinFns t = make_bin_fns(row, fr);
-        add_bbox(t, tris15 + (size_t)15 * tri, fr);
-        const float T = 2.384185791015625e-07f;       // |e1e2b| < 2^-22: t may underflow to +-0, either sign of e1e2d passes
-        const bool both = fabsf(t.nb) < T || !(t.nb == t.nb);
-        const float sgn = t.nb < 0.0f ? -1.0f : 1.0f;
-        const EdgeFn *fn[4] = { &t.n, &t.p, &t.q, &t.s };
-        float A0[4];
+    bool ok = true;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float su = sgn * fn[k]->cu, sv = sgn * fn[k]->cv;
-            // value at the (unpadded) origin corner of bin (0,0), margin folded in
-            const float base = sgn * fn[k]->c0 + fn[k]->m + su * fr.ulo + sv * fr.vlo;
-            it.Bu[k] = su * fr.du;
-            it.Bv[k] = sv * fr.dv;
-            const float inf = __builtin_huge_valf();
-            A0[k] = both ? inf : base + corner(su, fr.pad_lo, (float)BIN_L0 * fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, (float)BIN_L0 * fr.dv + fr.pad_hi);
-            it.A1[k] = both ? inf : base + corner(su, fr.pad_lo, (float)BIN_COARSE * fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, (float)BIN_COARSE * fr.dv + fr.pad_hi);
-            it.A2[k] = both ? inf : base + corner(su, fr.pad_lo, fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, fr.dv + fr.pad_hi);
-            if (both) { it.Bu[k] = 0.0f; it.Bv[k] = 0.0f; }
-        }
-        const float inf = __builtin_huge_valf();
-        if (t.bstate == BOX_VALID) {
-            // bin-index ranges, widened by 2^-18 (relative) against the rounding of this conversion
-            it.lou = (t.bu0 - fr.ulo - fr.pad_hi) / fr.du; it.hiu = (t.bu1 - fr.ulo - fr.pad_lo) / fr.du;
-            it.lov = (t.bv0 - fr.vlo - fr.pad_hi) / fr.dv; it.hiv = (t.bv1 - fr.vlo - fr.pad_lo) / fr.dv;
-            it.lou -= 3.814697265625e-06f * (1.0f + fabsf(it.lou)); it.hiu += 3.814697265625e-06f * (1.0f + fabsf(it.hiu));
-            it.lov -= 3.814697265625e-06f * (1.0f + fabsf(it.lov)); it.hiv += 3.814697265625e-06f * (1.0f + fabsf(it.hiv));
-        } else if (t.bstate == BOX_EMPTY) {
-            it.lou = it.lov = inf; it.hiu = it.hiv = -inf;
-        } else {
-            it.lou = it.lov = -inf; it.hiu = it.hiv = inf;
-        }
-        // level 0: the cell of 64x64 bins starting at bin (cx*64, cy*64)
-        const float I = (float)(cx * BIN_L0), J = (float)(cy * BIN_L0);
-        const int j0 = max((int)cy * BIN_L0, fr.j0), j1 = min((int)(cy + 1) * BIN_L0, fr.j1);
-        bool ok = j1 > j0 && (int)(cx * BIN_L0) < fr.nbu;
-#pragma unroll
-        for (int k = 0; k < 4; k++) ok = ok && (__builtin_fmaf(J, it.Bv[k], __builtin_fmaf(I, it.Bu[k], A0[k])) >= 0.0f);
-        ok = ok && (I + (float)BIN_L0 >= it.lou) && (I <= it.hiu) && (J + (float)BIN_L0 >= it.lov) && (J <= it.hiv);
-        pass0 = ok;
-    }
-    unsigned long long m0 = __ballot(pass0);
+    for (int k = 0; k < 4; k++) ok = ok && (__builtin_fmaf(J, u.Bv[k], __builtin_fmaf(I, u.Bu[k], A[k])) >= 0.0f);
+    return ok && (I + K >= u.lou) && (I <= u.hiu) && (J + K >= u.lov) && (J <= u.hiv);
+}
+
+struct BinFrameGrid { int nbu, fj0, fj1, cells_x, cy0, ncell; uint32_t fbase; };
+
+constexpr int BIN_PAIR_BUF = 4096;                    // pairs a workgroup stages in LDS between flushes (32 KiB)
+constexpr int BIN_DIRECT_SIDE = 32;                   // boxes up to 32 x 32 bins are tested bin by bin, flattened over the workgroup
+
+// Where the pairs of the huge items go: the workgroup's LDS buffer, allocated with an LDS atomic per level-2 step, and
+// once that is full straight to the global list (one global atomic per step -- only scenes of huge triangles get there).
+struct BinLargeSink {
+    uint32_t *s_keys, *s_vals;    // LDS, BIN_PAIR_BUF each
+    uint32_t *s_fill;             // LDS: slots handed out so far (may run past BIN_PAIR_BUF)
+    uint32_t *s_valid;            // LDS: slots [0, *s_valid) hold pairs (the step that did not fit any more lowers it)
+    uint32_t *g_count;            // the global list's length
+    BinPairs out;
+};
+
+// Walks one large item (wave-uniform `u`) through the three levels and emits its pairs.
+// `cells0` = the owner lane's level-0 verdicts for the first 64 cells (wave-uniform).
+__device__ __forceinline__ void bin_walk_large(const BinItem &u, uint32_t utri, const BinFrameGrid &gr, int lane,
+                                               const BinLargeSink &sink, unsigned long long cells0)
+{
 #ifdef MIRT_BIN_STATS
-    if (!FILL && lane == 0) atomicAdd(&bs.counters[2], (uint32_t)__popcll(m0));
+    uint32_t dbg_steps = 0, dbg_pairs = 0, dbg_l1 = 0;
 #endif
-    while (m0) {
-        const int src = __builtin_ctzll(m0);
-        m0 &= m0 - 1ull;
-        // the surviving lane's item, made wave-uniform
-        BinItem u;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { u.A1[k] = bcastf(it.A1[k], src); u.A2[k] = bcastf(it.A2[k], src); u.Bu[k] = bcastf(it.Bu[k], src); u.Bv[k] = bcastf(it.Bv[k], src); }
-        u.lou = bcastf(it.lou, src); u.hiu = bcastf(it.hiu, src); u.lov = bcastf(it.lov, src); u.hiv = bcastf(it.hiv, src);
-        const uint32_t utri = (uint32_t)__builtin_amdgcn_readlane((int)tri, src);
-        const uint32_t ufr = (uint32_t)__builtin_amdgcn_readlane((int)frame, src);
-        const uint32_t ucx = (uint32_t)__builtin_amdgcn_readlane((int)cx, src), ucy = (uint32_t)__builtin_amdgcn_readlane((int)cy, src);
-        const BinFrameDesc &fr = bs.frames[ufr];
-        const int nbu = fr.nbu, fj0 = fr.j0, fj1 = fr.j1;
-        const uint32_t fbase = fr.base;
-        // level 1: lane = coarse cell (8x8 bins) inside the level-0 cell
-        const int ci = (int)(ucx * BIN_L0) + (lane & 7) * BIN_COARSE, cj = (int)(ucy * BIN_L0) + (lane >> 3) * BIN_COARSE;
-        const float CI = (float)ci, CJ = (float)cj;
-        bool pass1 = ci < nbu && cj + BIN_COARSE > fj0 && cj < fj1;
-#pragma unroll
-        for (int k = 0; k < 4; k++) pass1 = pass1 && (__builtin_fmaf(CJ, u.Bv[k], __builtin_fmaf(CI, u.Bu[k], u.A1[k])) >= 0.0f);
-        pass1 = pass1 && (CI + (float)BIN_COARSE >= u.lou) && (CI <= u.hiu) && (CJ + (float)BIN_COARSE >= u.lov) && (CJ <= u.hiv);
-        unsigned long long m1 = __ballot(pass1);
+    for (int c0 = 0; c0 < gr.ncell; c0 += 64) {
+        // level 0: lane = cell of 64x64 bins
+        const int c = c0 + lane, cx = c % gr.cells_x, cy = gr.cy0 + c / gr.cells_x;
+        unsigned long long m0;
+        if (c0 == 0 && gr.ncell <= 64) m0 = cells0;
+        else m0 = __ballot(c < gr.ncell && cell_may_hit(u, u.A0, (float)(cx * BIN_L0), (float)(cy * BIN_L0), (float)BIN_L0));
+        while (m0) {
+            const int l0 = __builtin_ctzll(m0);
+            m0 &= m0 - 1ull;
+            const int ucx = __builtin_amdgcn_readlane(cx, l0), ucy = __builtin_amdgcn_readlane(cy, l0);
+            // level 1: lane = coarse cell (8x8 bins) inside the level-0 cell
+            const int ci = ucx * BIN_L0 + (lane & 7) * BIN_COARSE, cj = ucy * BIN_L0 + (lane >> 3) * BIN_COARSE;
+            const bool pass1 = ci < gr.nbu && cj + BIN_COARSE > gr.fj0 && cj < gr.fj1 && cell_may_hit(u, u.A1, (float)ci, (float)cj, (float)BIN_COARSE);
+            unsigned long long m1 = __ballot(pass1);
 #ifdef MIRT_BIN_STATS
-        if (!FILL && lane == 0) atomicAdd(&bs.counters[3], (uint32_t)__popcll(m1));
+            dbg_l1++;
 #endif
-        while (m1) {
-            const int cl = __builtin_ctzll(m1);
-            m1 &= m1 - 1ull;
-            // level 2: lane = bin inside coarse cell `cl`
-            const int i = (int)(ucx * BIN_L0) + (cl & 7) * BIN_COARSE + (lane & 7);
-            const int j = (int)(ucy * BIN_L0) + (cl >> 3) * BIN_COARSE + (lane >> 3);
-            const float FI = (float)i, FJ = (float)j;
-            bool pass2 = i < nbu && j >= fj0 && j < fj1;
-#pragma unroll
-            for (int k = 0; k < 4; k++) pass2 = pass2 && (__builtin_fmaf(FJ, u.Bv[k], __builtin_fmaf(FI, u.Bu[k], u.A2[k])) >= 0.0f);
-            pass2 = pass2 && (FI + 1.0f >= u.lou) && (FI <= u.hiu) && (FJ + 1.0f >= u.lov) && (FJ <= u.hiv);
-            if (pass2) {
-                const uint32_t bin = fbase + (uint32_t)j * nbu + i;
-                if (!FILL) {
-                    atomicAdd(&bs.bin_off[bin], 1u);                 // counts, scanned in place afterwards
+            while (m1) {
+                const int cl = __builtin_ctzll(m1);
+                m1 &= m1 - 1ull;
+                // level 2: lane = bin inside coarse cell `cl`
+                const int i = ucx * BIN_L0 + (cl & 7) * BIN_COARSE + (lane & 7);
+                const int j = ucy * BIN_L0 + (cl >> 3) * BIN_COARSE + (lane >> 3);
+                const bool pass2 = i < gr.nbu && j >= gr.fj0 && j < gr.fj1 && cell_may_hit(u, u.A2, (float)i, (float)j, 1.0f);
+                const unsigned long long m2 = __ballot(pass2);
+#ifdef MIRT_BIN_STATS
+                dbg_steps++; dbg_pairs += (uint32_t)__popcll(m2);
+#endif
+                if (!m2) continue;
+                const uint32_t np = (uint32_t)__popcll(m2), rank = (uint32_t)__popcll(m2 & ((1ull << lane) - 1ull));
+                const uint32_t key = gr.fbase + (uint32_t)j * gr.nbu + i;
+                uint32_t at0 = 0;
+                if (lane == 0) at0 = atomicAdd(sink.s_fill, np);
+                at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+                if (at0 + np <= (uint32_t)BIN_PAIR_BUF) {
+                    if (pass2) { sink.s_keys[at0 + rank] = key; sink.s_vals[at0 + rank] = utri; }
                 } else {
-                    const uint32_t slot = bs.bin_off[bin] + atomicAdd(&bs.bin_fill[bin], 1u);
-                    if (slot < bs.cap_entries) bs.entries[slot] = utri;
-                    else atomicExch(&bs.counters[1], 1u);
+                    if (lane == 0) {
+                        if (at0 < (uint32_t)BIN_PAIR_BUF) *sink.s_valid = at0;     // exactly one step straddles the end of the buffer
+                        at0 = atomicAdd(sink.g_count, np);
+                    }
+                    at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+                    if (pass2 && at0 + rank < sink.out.cap) { sink.out.keys[at0 + rank] = key; sink.out.vals[at0 + rank] = utri; }
                 }
             }
         }
     }
+#ifdef MIRT_BIN_STATS
+    if (lane == 0) {
+        uint32_t *c = sink.g_count;      // counters[0]; the statistics live behind it
+        atomicAdd(&c[2], 1u); atomicAdd(&c[3], dbg_l1); atomicAdd(&c[4], dbg_steps); atomicAdd(&c[5], dbg_pairs);
+        atomicMax(&c[6], dbg_steps);
+        if (dbg_steps > 100) atomicAdd(&c[7], 1u);
+    }
+#endif
 }
 
-template __global__ void k_bin<false>(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
-template __global__ void k_bin<true>(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinGridInfo);
+// what the flattened bin-by-bin tests need of a direct item, in LDS
+struct BinDirect {
+    float4 A2, Bu, Bv, box;       // box = {lou, hiu, lov, hiv}
+};
+
+__global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
+                                                   const OriginRow *__restrict__ light_tab, int n, BinSet bs, BinPairs out)
+{
+    __shared__ uint32_t s_keys[BIN_PAIR_BUF], s_vals[BIN_PAIR_BUF];
+    __shared__ BinDirect s_item[256];
+    __shared__ uint32_t s_org[256];                   // i_lo | j_lo << 16 of a direct item's box
+    __shared__ uint32_t s_ni[256];                    // its width in bins
+    __shared__ uint32_t s_pre[257];                   // exclusive prefix of the box sizes
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base, s_fill, s_valid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = (n + 255) / 256, nwork = nchunks * bs.nframes;
+    if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
+
+    // hands the staged pairs over to the global list (called by all threads)
+    auto flush = [&]() {
+        __syncthreads();
+        const uint32_t staged = min(s_fill, s_valid);
+        if (threadIdx.x == 0 && staged) s_base = atomicAdd(&bs.counters[0], staged);
+        __syncthreads();
+        const uint32_t base = s_base;
+        for (uint32_t i = threadIdx.x; i < staged; i += 256) {
+            const uint32_t at = base + i;
+            if (at < out.cap) { out.keys[at] = s_keys[i]; out.vals[at] = s_vals[i]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
+        __syncthreads();
+    };
+
+    for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int chunk = w / bs.nframes, frame = w - chunk * bs.nframes;
+        const uint32_t tri0 = (uint32_t)chunk * 256u, tri = tri0 + threadIdx.x;
+        const BinFrameDesc &fr = bs.frames[frame];
+        BinFrameGrid gr;
+        gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base;
+        gr.cells_x = (gr.nbu + BIN_L0 - 1) / BIN_L0; gr.cy0 = gr.fj0 / BIN_L0;
+        gr.ncell = gr.cells_x * ((gr.fj1 + BIN_L0 - 1) / BIN_L0 - gr.cy0);
+        const int nbu = gr.nbu, fj0 = gr.fj0, fj1 = gr.fj1;
+        BinItem it;
+        memset(&it, 0, sizeof it);
+        int kind = 0;                                     // 0: no bin can hold a hit, 1: direct (box of at most 32 x 32 bins), 2: huge (wave walks)
+#ifdef MIRT_BIN_STATS
+        int dbg_state = 0;
+#endif
+        int i_lo = 0, i_hi = -1, j_lo = 0, j_hi = -1;
+        unsigned long long cells = 0;                     // huge items: level-0 cells (first 64) that may hold a hit
+        if (tri < (uint32_t)n && fj1 > fj0) {
+            const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
+            TriBinFns t = make_bin_fns(row, fr);
+            add_bbox(t, tris15 + (size_t)15 * tri, fr);
+#ifdef MIRT_BIN_STATS
+            dbg_state = t.bstate == BOX_VALID ? 0 : (t.bstate == BOX_NONE ? 1 : 2);
+#endif
+            // t = e1e2b / e1e2d passes `t >= 0` with the "wrong" sign of e1e2d only if it comes out as -0, i.e. e1e2b is
+            // zero or the quotient underflows past the smallest subnormal 2^-149.  Binning runs only for operands the host
+            // has bounded (|coordinate| < 1e8, |negD| < 1e6: mirt_capi.hip `safe`), so |e1e2d| < 2^79 and the quotient
+            // cannot underflow unless |e1e2b| < 2^-70: below 2^-69 either sign of e1e2d is allowed.  (rect_may_hit keeps
+            // the scene-independent 2^-22; with that here, the handful of triangles of a 100 k soup whose plane passes
+            // within 1e-4 of the camera were put into every bin of the screen.)
+            const float T = 1.6940658945086007e-21f;
+            const bool both = fabsf(t.nb) < T || !(t.nb == t.nb);
+            const float sgn = t.nb < 0.0f ? -1.0f : 1.0f;
+            const EdgeFn *fn[4] = { &t.n, &t.p, &t.q, &t.s };
+            const float inf = __builtin_huge_valf();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float su = sgn * fn[k]->cu, sv = sgn * fn[k]->cv;
+                // value at the (unpadded) origin corner of bin (0,0), margin folded in
+                const float base = sgn * fn[k]->c0 + fn[k]->m + su * fr.ulo + sv * fr.vlo;
+                it.Bu[k] = both ? 0.0f : su * fr.du;
+                it.Bv[k] = both ? 0.0f : sv * fr.dv;
+                it.A0[k] = both ? inf : base + corner(su, fr.pad_lo, (float)BIN_L0 * fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, (float)BIN_L0 * fr.dv + fr.pad_hi);
+                it.A1[k] = both ? inf : base + corner(su, fr.pad_lo, (float)BIN_COARSE * fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, (float)BIN_COARSE * fr.dv + fr.pad_hi);
+                it.A2[k] = both ? inf : base + corner(su, fr.pad_lo, fr.du + fr.pad_hi) + corner(sv, fr.pad_lo, fr.dv + fr.pad_hi);
+            }
+            if (t.bstate == BOX_VALID) {
+                // bin-index ranges, widened by 2^-18 (relative) against the rounding of this conversion
+                it.lou = (t.bu0 - fr.ulo - fr.pad_hi) / fr.du; it.hiu = (t.bu1 - fr.ulo - fr.pad_lo) / fr.du;
+                it.lov = (t.bv0 - fr.vlo - fr.pad_hi) / fr.dv; it.hiv = (t.bv1 - fr.vlo - fr.pad_lo) / fr.dv;
+                it.lou -= 3.814697265625e-06f * (1.0f + fabsf(it.lou)); it.hiu += 3.814697265625e-06f * (1.0f + fabsf(it.hiu));
+                it.lov -= 3.814697265625e-06f * (1.0f + fabsf(it.lov)); it.hiv += 3.814697265625e-06f * (1.0f + fabsf(it.hiv));
+            } else if (t.bstate == BOX_EMPTY) {
+                it.lou = it.lov = inf; it.hiu = it.hiv = -inf;
+            } else {
+                it.lou = it.lov = -inf; it.hiu = it.hiv = inf;
+            }
+            // The bins the box admits: bin i passes `i + 1 >= lou && i <= hiu` exactly when ceil(lou) - 1 <= i <= floor(hiu);
+            // clamped to the frame's grid.  (NaN bounds fail every comparison, here and in cell_may_hit alike.)
+            const float flo_u = fmaxf(ceilf(it.lou) - 1.0f, 0.0f), fhi_u = fminf(floorf(it.hiu), (float)(nbu - 1));
+            const float flo_v = fmaxf(ceilf(it.lov) - 1.0f, (float)fj0), fhi_v = fminf(floorf(it.hiv), (float)(fj1 - 1));
+            if (flo_u <= fhi_u && flo_v <= fhi_v) {
+                i_lo = (int)flo_u; i_hi = (int)fhi_u; j_lo = (int)flo_v; j_hi = (int)fhi_v;
+                kind = (i_hi - i_lo < BIN_DIRECT_SIDE && j_hi - j_lo < BIN_DIRECT_SIDE) ? 1 : 2;
+            }
+            // Level 0 of a huge item by the lane itself: most of them (triangles a cube face sees edge-on or behind its
+            // plane have no usable box, so they land here) fail every 64x64-bin cell and never occupy the wave.
+            if (kind == 2) {
+                for (int c = 0; c < gr.ncell && c < 64; c++) {
+                    const int cx = c % gr.cells_x, cy = gr.cy0 + c / gr.cells_x;
+                    if (cell_may_hit(it, it.A0, (float)(cx * BIN_L0), (float)(cy * BIN_L0), (float)BIN_L0)) cells |= 1ull << c;
+                }
+                if (gr.ncell > 64) cells = ~0ull;          // more cells than mask bits (frames beyond 4096 x 4096 bins): the walk tests them
+                if (!cells) kind = 0;
+            }
+        }
+
+
+
+        // ---- direct items: constants to LDS, exclusive prefix of their box sizes over the workgroup ----
+        const uint32_t ni = (uint32_t)(i_hi - i_lo + 1);
+        const uint32_t nb = kind == 1 ? ni * (uint32_t)(j_hi - j_lo + 1) : 0u;
+        uint32_t incl = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        __syncthreads();                              // the previous work item's readers of the LDS tables are done
+        if (lane == 63) s_wave[wave] = incl;
+        if (kind == 1) {
+            BinDirect d;
+            d.A2 = make_float4(it.A2[0], it.A2[1], it.A2[2], it.A2[3]);
+            d.Bu = make_float4(it.Bu[0], it.Bu[1], it.Bu[2], it.Bu[3]);
+            d.Bv = make_float4(it.Bv[0], it.Bv[1], it.Bv[2], it.Bv[3]);
+            d.box = make_float4(it.lou, it.hiu, it.lov, it.hiv);
+            s_item[threadIdx.x] = d;
+            s_org[threadIdx.x] = (uint32_t)i_lo | ((uint32_t)j_lo << 16);
+            s_ni[threadIdx.x] = ni;
+        }
+        __syncthreads();
+        const uint32_t t0w = s_wave[0], t1w = s_wave[1], t2w = s_wave[2], t3w = s_wave[3];
+        s_pre[threadIdx.x] = (wave > 0 ? t0w : 0u) + (wave > 1 ? t1w : 0u) + (wave > 2 ? t2w : 0u) + incl - nb;
+        const uint32_t T = t0w + t1w + t2w + t3w;
+        if (threadIdx.x == 0) s_pre[256] = T;
+
+#ifdef MIRT_BIN_STATS
+        if (kind == 2) { atomicAdd(&bs.counters[11 + dbg_state], 1u); if (frame == 0) atomicAdd(&bs.counters[14], 1u); }
+        if (threadIdx.x == 0) { atomicAdd(&bs.counters[8], T); atomicMax(&bs.counters[9], T); }
+        { const unsigned long long md = __ballot(kind == 1); if (lane == 0) atomicAdd(&bs.counters[10], (uint32_t)__popcll(md)); }
+#endif
+        // ---- flattened bin-by-bin tests: thread t of a round takes test t ----
+        for (uint32_t r0 = 0; r0 < T; r0 += 256) {
+            __syncthreads();                          // s_pre written / the previous round's appends counted
+            if (s_fill + 256u > (uint32_t)BIN_PAIR_BUF) flush();
+            const uint32_t t = r0 + threadIdx.x;
+            bool pass = false;
+            uint32_t key = 0, val = 0;
+            if (t < T) {
+                uint32_t lo = 0, hi = 256;            // the item whose range [s_pre[i], s_pre[i+1]) holds t
+#pragma unroll
+                for (int step = 0; step < 8; step++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_pre[mid] <= t) lo = mid; else hi = mid;
+                }
+                const uint32_t b = t - s_pre[lo], wi = s_ni[lo], org = s_org[lo];
+                const uint32_t recip = 65536u / wi + 1u;             // b / wi == (b * recip) >> 16 for b < 1024, wi <= 32
+                const uint32_t dj = (b * recip) >> 16, di = b - dj * wi;
+                const int i = (int)(org & 0xFFFFu) + (int)di, j = (int)(org >> 16) + (int)dj;
+                const BinDirect d = s_item[lo];
+                const float FI = (float)i, FJ = (float)j;
+                pass = (__builtin_fmaf(FJ, d.Bv.x, __builtin_fmaf(FI, d.Bu.x, d.A2.x)) >= 0.0f) &&
+                       (__builtin_fmaf(FJ, d.Bv.y, __builtin_fmaf(FI, d.Bu.y, d.A2.y)) >= 0.0f) &&
+                       (__builtin_fmaf(FJ, d.Bv.z, __builtin_fmaf(FI, d.Bu.z, d.A2.z)) >= 0.0f) &&
+                       (__builtin_fmaf(FJ, d.Bv.w, __builtin_fmaf(FI, d.Bu.w, d.A2.w)) >= 0.0f) &&
+                       (FI + 1.0f >= d.box.x) && (FI <= d.box.y) && (FJ + 1.0f >= d.box.z) && (FJ <= d.box.w);   // = cell_may_hit(.., A2, i, j, 1)
+                key = gr.fbase + (uint32_t)j * (uint32_t)nbu + (uint32_t)i;
+                val = tri0 + lo;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                uint32_t at0 = 0;
+                if (lane == 0) at0 = atomicAdd(&s_fill, (uint32_t)__popcll(m));
+                at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+                if (pass) {
+                    const uint32_t at = at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    s_keys[at] = key; s_vals[at] = val;               // fits: the round started with room for 256
+                }
+            }
+        }
+
+        // ---- huge items: the wave walks them one at a time, pairs into the same LDS buffer ----
+        __syncthreads();                              // no flattened round (which counts on its 256 free slots) is still appending
+        {
+            BinLargeSink sink = { s_keys, s_vals, &s_fill, &s_valid, &bs.counters[0], out };
+            for (unsigned long long ml = __ballot(kind == 2); ml;) {
+                const int src = __builtin_ctzll(ml);
+                ml &= ml - 1ull;
+                BinItem u;                            // the item, made wave-uniform
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    u.A0[k] = bcastf(it.A0[k], src); u.A1[k] = bcastf(it.A1[k], src); u.A2[k] = bcastf(it.A2[k], src);
+                    u.Bu[k] = bcastf(it.Bu[k], src); u.Bv[k] = bcastf(it.Bv[k], src);
+                }
+                u.lou = bcastf(it.lou, src); u.hiu = bcastf(it.hiu, src); u.lov = bcastf(it.lov, src); u.hiv = bcastf(it.hiv, src);
+                const uint32_t utri = (uint32_t)__builtin_amdgcn_readlane((int)tri, src);
+                const unsigned long long ucells = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cells >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cells, src);
+                bin_walk_large(u, utri, gr, lane, sink, ucells);
+            }
+        }
+    }
+    flush();
+}
+
+// bin_off[b] = first position of a key >= b in the sorted pair list (b = 0 .. nbins; bin_off[nbins] = total)
+__global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict__ sorted_keys, const uint32_t *__restrict__ total_ptr,
+                                                     uint32_t cap, uint32_t nbins, uint32_t *__restrict__ bin_off)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nbins) return;
+    const uint32_t total = min(*total_ptr, cap);
+    uint32_t lo = 0, hi = total;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sorted_keys[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    bin_off[b] = lo;
+}
 
 // ---- k_rt_binned: fused primary + shadow + shade + resolve over the binned candidates ---------------
 //

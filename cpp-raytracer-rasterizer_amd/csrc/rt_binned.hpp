@@ -49,17 +49,16 @@ struct BinSet {
     int nframes;
     uint32_t nbins;               // total bins over all frames
     uint32_t *bin_off;            // nbins + 1: exclusive scan of the counts (bin_off[nbins] = total entries)
-    uint32_t *bin_fill;           // nbins: fill cursors
     uint32_t *entries;            // candidate triangle indices
     uint32_t cap_entries;
-    uint32_t *counters;           // [0] total entries, [1] overflow flag
+    uint32_t *counters;           // [0] pairs produced by k_bin_pairs (may exceed the capacity: then the frame is redone)
 };
 
-// How the level-0 cells of all frames are numbered per triangle (rt_binned.hip: k_bin).
-struct BinGridInfo {
-    uint32_t cells_per_tri;      // level-0 cells per triangle over all frames
-    uint32_t cam_cells, cam_cells_x, cam_cell_y0;
-    uint32_t face_cells_x;       // level-0 cells per cube-face side (cube_bins / 64); every face has face_cells_x^2
+// The unsorted (bin, triangle) pair list k_bin_pairs writes and bin_sort.hip orders by bin.
+struct BinPairs {
+    uint32_t *keys;               // bin ids
+    uint32_t *vals;               // triangle indices
+    uint32_t cap;
 };
 
 // affine edge function over (u,v) with its safety margin
@@ -114,7 +113,7 @@ __device__ __forceinline__ TriBinFns make_bin_fns(const OriginRow &r, const BinF
 //    of the projection (BOX_VALID);
 //  * all three clearly behind (rw.g < 0): the projected lines bound the ANTIPODAL triangle, inside which the three
 //    functions have the rejecting sign; a point within margin of all three accepting sides would need d >= r_in.  If
-//    d < r_in/8 no ray of this family can be accepted at all (BOX_EMPTY);
+//    d < r_in/2 (r_in bounded from below) no ray of this family can be accepted at all (BOX_EMPTY);
 //  * anything else (a vertex near the plane, degenerate projections, NaN) keeps BOX_NONE and relies on the edge
 //    functions, which are always valid.
 __device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const BinFrameDesc &fr)
@@ -153,7 +152,11 @@ __device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const B
     const float ds = t.s.m / sqrtf(t.s.cu * t.s.cu + t.s.cv * t.s.cv);
     const float d = fmaxf(fmaxf(dp, dq), ds) + pad;
     if (behind == 3) {
-        if (d < 0.125f * rin) t.bstate = BOX_EMPTY;                // needs d < r_in; NaN or rin == 0 keep BOX_NONE
+        // needs d < r_in = 2*area/perimeter.  r_in is taken from below: every vertex may be off by `pad` (area changes by
+        // at most pad*perimeter, doubled) and the cross product cancels (2^-21 of its two products); half of that bound
+        // is the threshold.  NaN or a vanishing area keep BOX_NONE.
+        const float area_lo = area2 - 2.0f * pad * per - 4.76837158203125e-07f * (fabsf(ax * by) + fabsf(ay * bx));
+        if (d < 0.5f * (area_lo / per)) t.bstate = BOX_EMPTY;
         return;
     }
     // front: the region {dist_i >= -d} is the triangle with every edge line pushed out by d, i.e. the triangle whose

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "mirt_math.hpp"
+#include "mirt_math2.hpp"
 #include "../../include/mirt.h"
 
 namespace mirt {
@@ -78,6 +79,55 @@ __device__ __forceinline__ bool maybe_hit(const TestDots &d)
     const float b = __uint_as_float(__float_as_uint(d.qv) ^ sgn);
     const float slack = __builtin_fmaf(fabsf(d.den), 1.00000095367431640625f, -(a + b));
     return fminf(fminf(a, b), slack) >= -2.384185791015625e-07f;
+}
+
+// ---- the same for two rays per lane (packed FP32, mirt_math2.hpp) ------------------------------------------
+struct TestDots2 { f2 den, pu, qv; };
+
+__device__ __forceinline__ TestDots2 test_dots2(const float4 &r0, const float4 &r1, const float4 &r2, const v3p &nd)
+{
+    TestDots2 d;
+    d.den = splat2(r0.x) * nd.x + splat2(r0.y) * nd.y + splat2(r0.z) * nd.z;
+    d.pu = splat2(r1.x) * nd.x + splat2(r1.y) * nd.y + splat2(r1.z) * nd.z;
+    d.qv = splat2(r2.x) * nd.x + splat2(r2.y) * nd.y + splat2(r2.z) * nd.z;
+    return d;
+}
+__device__ __forceinline__ TestDots dots_half(const TestDots2 &d, int h)
+{
+    TestDots r;
+    r.den = h ? d.den.y : d.den.x; r.pu = h ? d.pu.y : d.pu.x; r.qv = h ? d.qv.y : d.qv.x;
+    return r;
+}
+
+// maybe_hit (rt_common.hpp) for both rays: a = s*pu, b = s*qv, D = s*den with s = +-1 carrying den's sign --
+// multiplying by +-1 is exact, so a, b and D have the very bits the scalar filter's xor / fabs produce.
+__device__ __forceinline__ void maybe_hit2(const TestDots2 &d, bool *m0, bool *m1)
+{
+    const f2 s = { __uint_as_float((__float_as_uint(d.den.x) & 0x80000000u) | 0x3f800000u),
+                   __uint_as_float((__float_as_uint(d.den.y) & 0x80000000u) | 0x3f800000u) };
+    const f2 a = d.pu * s, b = d.qv * s, D = d.den * s;
+    const f2 slack = __builtin_elementwise_fma(D, splat2(1.00000095367431640625f), -(a + b));
+    *m0 = fminf(fminf(a.x, b.x), slack.x) >= -2.384185791015625e-07f;
+    *m1 = fminf(fminf(a.y, b.y), slack.y) >= -2.384185791015625e-07f;
+}
+
+// Dots and filter verdicts of P rays against one origin row: packed when P == 2 and the filter is on.
+template <int P, bool FILTER>
+__device__ __forceinline__ void test_rays(const float4 &r0, const float4 &r1, const float4 &r2, const v3 (&nd)[P],
+                                          TestDots (&d)[P], bool (&maybe)[P])
+{
+    if constexpr (P == 2 && FILTER) {
+        const TestDots2 t = test_dots2(r0, r1, r2, join3(nd[0], nd[1]));
+        maybe_hit2(t, &maybe[0], &maybe[1]);
+        d[0] = dots_half(t, 0);
+        d[1] = dots_half(t, 1);
+    } else {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            d[p] = test_dots(r0, r1, r2, nd[p]);
+            maybe[p] = !FILTER || maybe_hit(d[p]);
+        }
+    }
 }
 
 // The accept test and hit point exactly as the reference computes them (raytracer.cpp:237-242).

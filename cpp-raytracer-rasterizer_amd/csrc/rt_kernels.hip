@@ -91,13 +91,15 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
 #pragma unroll 2
                 for (int j = 0; j < cnt; j++) {
                     const float4 r0 = s_tab[3 * j], r1 = s_tab[3 * j + 1], r2 = s_tab[3 * j + 2];
+                    TestDots d[P];
+                    bool maybe[P];
+                    test_rays<P, FILTER>(r0, r1, r2, nd, d, maybe);
 #pragma unroll
                     for (int p = 0; p < P; p++) {
-                        const TestDots d = test_dots(r0, r1, r2, nd[p]);
-                        if (!FILTER || maybe_hit(d)) {
+                        if (maybe[p]) {
                             v3 hp;
                             float dist;
-                            if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), cam, &hp, &dist)) {
+                            if (exact_hit(d[p], r0.w, f.tris15 + (size_t)15 * (base + j), cam, &hp, &dist)) {
                                 any[p] = true;
                                 if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = base + j; pos[p] = hp; }
                             }
@@ -153,14 +155,16 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
 #pragma unroll 2
                     for (int j = 0; j < cnt; j++) {
                         const float4 r0 = s_tab[3 * j], r1 = s_tab[3 * j + 1], r2 = s_tab[3 * j + 2];
+                        // shadow ray: start = light, dir = -rDir, so negD = rDir (:310, :229)
+                        TestDots d[P];
+                        bool maybe[P];
+                        test_rays<P, FILTER>(r0, r1, r2, rd, d, maybe);
 #pragma unroll
                         for (int p = 0; p < P; p++) {
-                            // shadow ray: start = light, dir = -rDir, so negD = rDir (:310, :229)
-                            const TestDots d = test_dots(r0, r1, r2, rd[p]);
-                            if (live[p] && (!FILTER || maybe_hit(d))) {
+                            if (live[p] && maybe[p]) {
                                 v3 hp;
                                 float dist;
-                                if (exact_hit(d, r0.w, f.tris15 + (size_t)15 * (base + j), L, &hp, &dist)) {
+                                if (exact_hit(d[p], r0.w, f.tris15 + (size_t)15 * (base + j), L, &hp, &dist)) {
                                     // min over accepted hits < thr  <=>  some accepted hit < thr (any-hit is exact)
                                     if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);
                                 }
@@ -271,13 +275,15 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
 #pragma unroll 2
             for (int j = 0; j < n; j++) {
                 const float4 r0 = s_cam[3 * j], r1 = s_cam[3 * j + 1], r2 = s_cam[3 * j + 2];
+                TestDots d[P];
+                bool maybe[P];
+                test_rays<P, FILTER>(r0, r1, r2, nd, d, maybe);
 #pragma unroll
                 for (int p = 0; p < P; p++) {
-                    const TestDots d = test_dots(r0, r1, r2, nd[p]);
-                    if (!FILTER || maybe_hit(d)) {
+                    if (maybe[p]) {
                         v3 hp;
                         float dist;
-                        if (exact_hit_lds(d, r0.w, s_geo + 3 * j, cam, &hp, &dist)) {
+                        if (exact_hit_lds(d[p], r0.w, s_geo + 3 * j, cam, &hp, &dist)) {
                             any[p] = true;
                             if (best_d[p] >= dist) { best_d[p] = dist; best_i[p] = j; pos[p] = hp; }   // :243-247
                         }
@@ -321,13 +327,15 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
 #pragma unroll 2
                 for (int j = 0; j < n; j++) {
                     const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
+                    TestDots d[P];
+                    bool maybe[P];
+                    test_rays<P, FILTER>(r0, r1, r2, rd, d, maybe);          // negD = rDir (:310, :229)
 #pragma unroll
                     for (int p = 0; p < P; p++) {
-                        const TestDots d = test_dots(r0, r1, r2, rd[p]);     // negD = rDir (:310, :229)
-                        if (live[p] && (!FILTER || maybe_hit(d))) {
+                        if (live[p] && maybe[p]) {
                             v3 hp;
                             float dist;
-                            if (exact_hit_lds(d, r0.w, s_geo + 3 * j, L, &hp, &dist))
+                            if (exact_hit_lds(d[p], r0.w, s_geo + 3 * j, L, &hp, &dist))
                                 if (dist < thr[p]) live[p] = false, D[p] = V3(0.0f, 0.0f, 0.0f);   // :313-314
                         }
                     }

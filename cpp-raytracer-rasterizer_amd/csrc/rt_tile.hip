@@ -13,7 +13,6 @@
 // been accepted by any ray of the wave).  Per-triangle normalised normals and colours sit in LDS too, and each
 // workgroup renders several tiles per wave so the table build is amortised.
 #include "rt_binned.hpp"
-#include "mirt_math2.hpp"
 
 #include <float.h>
 
@@ -304,35 +303,6 @@ __global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
 // 64/TW rows below it.  Every multiply and add of the two rays shares one packed instruction (mirt_math2.hpp), the
 // LDS rows of a candidate triangle are read once for both rays, and the per-tile work (candidate masks, direction-box
 // reductions) is spread over twice the pixels.  No supersampling here (k_rt_tile<16, true> keeps that).
-
-struct TestDots2 { f2 den, pu, qv; };
-
-__device__ __forceinline__ TestDots2 test_dots2(const float4 &r0, const float4 &r1, const float4 &r2, const v3p &nd)
-{
-    TestDots2 d;
-    d.den = splat2(r0.x) * nd.x + splat2(r0.y) * nd.y + splat2(r0.z) * nd.z;
-    d.pu = splat2(r1.x) * nd.x + splat2(r1.y) * nd.y + splat2(r1.z) * nd.z;
-    d.qv = splat2(r2.x) * nd.x + splat2(r2.y) * nd.y + splat2(r2.z) * nd.z;
-    return d;
-}
-__device__ __forceinline__ TestDots dots_half(const TestDots2 &d, int h)
-{
-    TestDots r;
-    r.den = h ? d.den.y : d.den.x; r.pu = h ? d.pu.y : d.pu.x; r.qv = h ? d.qv.y : d.qv.x;
-    return r;
-}
-
-// maybe_hit (rt_common.hpp) for both rays: a = s*pu, b = s*qv, D = s*den with s = +-1 carrying den's sign --
-// multiplying by +-1 is exact, so a, b and D have the very bits the scalar filter's xor / fabs produce.
-__device__ __forceinline__ void maybe_hit2(const TestDots2 &d, bool *m0, bool *m1)
-{
-    const f2 s = { __uint_as_float((__float_as_uint(d.den.x) & 0x80000000u) | 0x3f800000u),
-                   __uint_as_float((__float_as_uint(d.den.y) & 0x80000000u) | 0x3f800000u) };
-    const f2 a = d.pu * s, b = d.qv * s, D = d.den * s;
-    const f2 slack = __builtin_elementwise_fma(D, splat2(1.00000095367431640625f), -(a + b));
-    *m0 = fminf(fminf(a.x, b.x), slack.x) >= -2.384185791015625e-07f;
-    *m1 = fminf(fminf(a.y, b.y), slack.y) >= -2.384185791015625e-07f;
-}
 
 template <int TW>
 __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty, const TileTables &tb)
