@@ -92,7 +92,9 @@ __device__ __forceinline__ TriBinFns make_bin_fns(const OriginRow &r, const BinF
     t.s.c0 = t.n.c0 - t.p.c0 - t.q.c0;
     t.s.cu = t.n.cu - t.p.cu - t.q.cu;
     t.s.cv = t.n.cv - t.p.cv - t.q.cv;
-    t.s.m = 2.0f * (t.n.m + t.p.m + t.q.m);      // also absorbs the filter's D*2^-20 relative slack
+    // s = n - p - q term by term: the three margins add up; the filter's own slack on top is D*2^-20 <= 2^-3 * m_n (m_n is
+    // 2^-17 * |e1e2|_1 * dmax >= 2^-17 * D), so a quarter more covers it
+    t.s.m = 1.25f * (t.n.m + t.p.m + t.q.m);
     t.nb = r.r0.w;
     t.bu0 = t.bu1 = t.bv0 = t.bv1 = 0.0f;
     t.bstate = BOX_NONE;
