@@ -2,6 +2,7 @@
 // library stream, staging buffers and the per-call statistics.  No CPU fallback: without a gfx950 device
 // every compute entry point returns MIRT_ERR_NO_DEVICE.
 #include "bin_sort.hpp"
+#include "cull.hpp"
 #include "dof.hpp"
 #include "rt_common.hpp"
 #include "raster_common.hpp"
@@ -44,6 +45,7 @@ struct RtBinnedFrame {
 };
 template <bool AA> __global__ void k_rt_binned(const RtBinnedFrame);
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
+__global__ void k_cull(const float *, int, const CullParams, uint8_t *);
 
 namespace {
 
@@ -817,6 +819,34 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
     else HIP_TRY(hipMemsetAsync(g.d_culled, 0, (size_t)n, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     g.scene_version++;
+    return MIRT_OK;
+}
+
+// The cull step on the device, for the uploaded scene: no host copy of the flags in either direction.
+extern "C" int mirt_cull_device(const mirt_view *view, int flags)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!view) return fail(MIRT_ERR_INVALID_ARGUMENT, "view must not be NULL");
+    if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
+    if (view->width <= 0 || view->height <= 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "frame %d x %d", view->width, view->height);
+    CullParams cp;
+    cull_setup(view, flags, &cp);
+    HIP_TRY(sync_all());                         // frames in flight read the flags
+    hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, g.stream, g.d_tris, g.n, cp, g.d_culled);
+    HIP_TRY(hipGetLastError());
+    g.scene_version++;
+    return MIRT_OK;
+}
+
+extern "C" int mirt_scene_get_culled(uint8_t *culled, int n)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
+    if (!culled || n != g.n) return fail(MIRT_ERR_INVALID_ARGUMENT, "cull array has %d entries, scene has %d triangles", n, g.n);
+    HIP_TRY(sync_all());
+    HIP_TRY(hipMemcpy(culled, g.d_culled, (size_t)n, hipMemcpyDeviceToHost));
     return MIRT_OK;
 }
 

@@ -22,6 +22,8 @@
 
 #include <limits.h>
 
+#include "cull.hpp"
+
 namespace mirt {
 
 // ---- VertexShader (rasteriser.cpp:532-546) ------------------------------------------------------------
@@ -456,6 +458,15 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     hipLaunchKernelGGL(k_raster_resolve, dim3((f.W + 255) / 256, band_rows), dim3(256), 0, stream, f);
     end(MIRT_K_RASTER_RESOLVE);
     return hipGetLastError() == hipSuccess ? MIRT_OK : MIRT_ERR_HIP;
+}
+
+// ---- the cull step of Update() on the device (rasteriser.cpp:404-447): one thread per triangle ----
+// The per-frame constants come from the host (cull_setup: acosf / tanf from the host's libm, as in the reference); the
+// per-triangle arithmetic is cull_one, the very function mirt_cull runs on the host.
+__global__ __launch_bounds__(256) void k_cull(const float *__restrict__ tris15, int n, const CullParams cp, uint8_t *__restrict__ culled)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) culled[i] = cull_one(tris15 + (size_t)15 * i, cp);
 }
 
 }  // namespace mirt

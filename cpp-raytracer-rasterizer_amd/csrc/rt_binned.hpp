@@ -147,7 +147,6 @@ __device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const B
     const float ax = us[1] - us[0], ay = vs[1] - vs[0], bx = us[2] - us[0], by = vs[2] - vs[0], cx = us[2] - us[1], cy = vs[2] - vs[1];
     const float area2 = fabsf(ax * by - ay * bx);
     const float per = sqrtf(ax * ax + ay * ay) + sqrtf(bx * bx + by * by) + sqrtf(cx * cx + cy * cy);
-    const float rin = area2 / per;
     // margin distances of the three edge functions, in (u,v) units
     const float dp = t.p.m / sqrtf(t.p.cu * t.p.cu + t.p.cv * t.p.cv);
     const float dq = t.q.m / sqrtf(t.q.cu * t.q.cu + t.q.cv * t.q.cv);

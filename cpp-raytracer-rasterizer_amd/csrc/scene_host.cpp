@@ -4,8 +4,14 @@
 #include "mirt_math.hpp"
 #include "../../include/mirt.h"
 
+#include "cull.hpp"
+
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 using namespace mirt;
 
@@ -118,44 +124,92 @@ extern "C" int mirt_scene_soup(uint32_t seed, int n, float s, float *tris15)
     return n;
 }
 
-// The cull step of the rasteriser's Update(), rasteriser.cpp:385-447, InCuboid :451-458.
-extern "C" int mirt_cull(const float *tris15, int n, const mirt_view *view, int flags, uint8_t *culled)
+// LoadSTL::LoadSTLFile + split (rasteriser/Source/LoadSTL.cpp:17-97): an ASCII STL as the reference reads it -- every
+// line containing "outer" is followed by three vertex lines, split at single spaces with empty tokens and the word
+// "vertex" dropped, the first three tokens through atof; afterwards every coordinate is multiplied by -scale (the
+// reference: 0.05f) and the normal recomputed (Triangle::ComputeNormal).  "facet normal", "endloop", "solid" lines are
+// never looked at, exactly as there.  A vertex line with fewer than three tokens is undefined behaviour in the reference
+// (out-of-range vector index); here it ends the load with MIRT_ERR_INVALID_ARGUMENT.
+extern "C" int mirt_scene_load_stl(const char *path, float scale, const float *colour3, float *tris15, int max_tris)
 {
-    if (!tris15 || !view || !culled || n < 0) return MIRT_ERR_INVALID_ARGUMENT;
+    if (!path || !colour3 || (tris15 && max_tris < 0)) return MIRT_ERR_INVALID_ARGUMENT;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return MIRT_ERR_INVALID_ARGUMENT;
+    std::string line;
+    auto getline = [&](std::string &out) -> bool {             // std::getline(stream, line): up to '\n', which is dropped
+        out.clear();
+        int c;
+        bool any = false;
+        while ((c = std::fgetc(f)) != EOF) {
+            any = true;
+            if (c == '\n') return true;
+            out.push_back((char)c);
+        }
+        return any;
+    };
+    auto split = [](const std::string &str, std::vector<std::string> &tok) {      // LoadSTL::split, :84-97
+        tok.clear();
+        size_t a = 0;
+        while (a <= str.size()) {
+            size_t b = str.find(' ', a);
+            if (b == std::string::npos) b = str.size();
+            const std::string t = str.substr(a, b - a);
+            if (t.size() > 0 && t != "vertex") tok.push_back(t);
+            a = b + 1;
+        }
+    };
+    int n = 0, rc = 0;
+    std::vector<std::string> tok;
+    while (getline(line)) {
+        if (line.find("outer") == std::string::npos) continue;                    // :35
+        float v[9];
+        for (int i = 0; i < 3; i++) {                                             // :40-57
+            std::string vl;
+            getline(vl);
+            split(vl, tok);
+            if (tok.size() < 3) { rc = MIRT_ERR_INVALID_ARGUMENT; break; }
+            for (int c = 0; c < 3; c++) v[3 * i + c] = (float)std::atof(tok[c].c_str());
+        }
+        if (rc) break;
+        if (tris15 && n < max_tris) {
+            float *t = tris15 + (size_t)15 * n;
+            for (int c = 0; c < 9; c++) t[c] = v[c] * -scale;                     // :66-76 (x, z, y of v0, v1, v2: order is irrelevant)
+            t[12] = colour3[0]; t[13] = colour3[1]; t[14] = colour3[2];           // :22
+            compute_normal(t);                                                    // :78
+        }
+        n++;
+    }
+    std::fclose(f);
+    return rc ? rc : n;
+}
+
+// The per-frame constants of the cull step (rasteriser.cpp:385-402); host libm for acosf / tanf, as the reference.
+void mirt::cull_setup(const mirt_view *view, int flags, CullParams *cp)
+{
+    memcpy(cp->cam, view->pos, 12);
+    memcpy(cp->rot, view->rot, 36);
     const v3 cam = ld3(view->pos);
-    const float *rot = view->rot;
-    const v3 fVec = normalize3(vec_mul_mat3(V3(0, 0, 1.0f), rot));                  // :385
+    const v3 fVec = normalize3(vec_mul_mat3(V3(0, 0, 1.0f), view->rot));            // :385
     const float nearz = cam.z + fVec.z * 0.1f, farz = cam.z + fVec.z * 15.0f;       // :386
     const float w = (float)view->width, h = (float)view->height;
     const v3 t = V3(0.0f, -h / 2.0f, view->focal), b = V3(0.0f, h / 2.0f, view->focal);
     const float cy = dot3(t, b) / (length3(t) * length3(b));                        // :394
     const float rfovy = acosf(cy);                                                  // :395
     const float aspect = w / h;
-    float tr[16];
-    memset(tr, 0, sizeof tr);
-    tr[0] = (1.0f / tanf(rfovy / 2.0f)) / aspect;                                   // transform[0][0] :398
-    tr[5] = (1.0f / tanf(rfovy / 2.0f));                                            // transform[1][1] :399
-    tr[10] = farz / (farz - nearz);                                                 // transform[2][2] :400
-    tr[14] = 1.0f;                                                                  // transform[3][2] :401-402
-    for (int i = 0; i < n; i++) {
-        const float *p = tris15 + (size_t)15 * i;
-        int c = 0;
-        if (flags & 1)
-            if (dot3(sub3(ld3(p), cam), ld3(p + 9)) > 0.0f) c = 1;                  // :408-414
-        if ((flags & 2) && !c) {
-            bool inside[3];
-            for (int k = 0; k < 3; k++) {
-                const v3 q = vec_mul_mat3(sub3(ld3(p + 3 * k), cam), rot);          // :423-425
-                const float v[4] = { q.x, q.y, q.z, 1.0f };
-                float o[4];
-                for (int j = 0; j < 4; j++)      // vec4 * mat4, raytracer/glm/detail/type_mat4x4.inl:664-675
-                    o[j] = tr[j * 4 + 0] * v[0] + tr[j * 4 + 1] * v[1] + tr[j * 4 + 2] * v[2] + tr[j * 4 + 3] * v[3];
-                const float X = o[0] / o[3], Y = o[1] / o[3], Z = o[2] / o[3];      // :435-437
-                inside[k] = X >= -1.0f && X <= 1.0f && Y >= -1.0f && Y <= 1.0f && Z >= 0.0f && Z <= 1.0f;
-            }
-            if (!inside[0] && !inside[1] && !inside[2]) c = 1;                      // :444-445
-        }
-        culled[i] = (uint8_t)c;
-    }
+    memset(cp->tr, 0, sizeof cp->tr);
+    cp->tr[0] = (1.0f / tanf(rfovy / 2.0f)) / aspect;                               // transform[0][0] :398
+    cp->tr[5] = (1.0f / tanf(rfovy / 2.0f));                                        // transform[1][1] :399
+    cp->tr[10] = farz / (farz - nearz);                                             // transform[2][2] :400
+    cp->tr[14] = 1.0f;                                                              // transform[3][2] :401-402
+    cp->flags = flags;
+}
+
+// The cull step of the rasteriser's Update(), rasteriser.cpp:385-447, InCuboid :451-458.
+extern "C" int mirt_cull(const float *tris15, int n, const mirt_view *view, int flags, uint8_t *culled)
+{
+    if (!tris15 || !view || !culled || n < 0) return MIRT_ERR_INVALID_ARGUMENT;
+    CullParams cp;
+    cull_setup(view, flags, &cp);
+    for (int i = 0; i < n; i++) culled[i] = cull_one(tris15 + (size_t)15 * i, cp);
     return MIRT_OK;
 }

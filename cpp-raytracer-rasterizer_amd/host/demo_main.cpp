@@ -1,7 +1,7 @@
 // demo_main.cpp -- the reference's main() loops (raytracer.cpp:113-178, rasteriser.cpp:101-149) on top of
 // mirt_draw.hpp, without SDL: a heap surface stands in for the window, one Update()+Draw() per "loop".
-//   demo_main rt|rtsoft|rtaa|rtdof|raster|rasterdof [width height [out.bmp [out.xrgb]]]
-//   (rtsoft: SOFT_SHADOWS_ENABLED, rtaa: AA_ENABLED, *dof: DOF_ENABLED)
+//   demo_main rt|rtsoft|rtaa|rtdof|raster|rasterdof|rasterstl [width height [out.bmp [out.xrgb [model.stl]]]]
+//   (rtsoft: SOFT_SHADOWS_ENABLED, rtaa: AA_ENABLED, *dof: DOF_ENABLED, rasterstl: the CUSTOM_MODEL build, culled on the GPU)
 // Writes a BMP screenshot (what SDL_SaveBMP(screen, "screenshot.bmp") does at :175/:147) and, optionally, the
 // raw XRGB words so tests can compare them with the oracle.
 #include "mirt_draw.hpp"
@@ -45,7 +45,13 @@ int main(int argc, char **argv)
             app.screen = screen;
             app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // rasteriser.cpp:104
             check(mirt_init(0), "mirt_init");
-            app.LoadTestModel();                                     // :112
+            if (which == "rasterstl") {                              // #ifdef CUSTOM_MODEL (:106-110)
+                app.LoadSTLFile(argc > 6 ? argv[6] : "Source/enemy1.stl");
+                app.cameraPos = vec3(0, -0.5f, -5.0f);
+                app.GPU_CULL = true;
+            } else {
+                app.LoadTestModel();                                 // :112
+            }
             app.cameraRot[1][1] = 1.01f;                             // :115 (sic)
             for (int loop = 0; loop < 2; loop++) {
                 app.Update();

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -170,7 +171,21 @@ struct Rasteriser {
         for (int i = 0; i < 30; i++) { std::memcpy(&triangles[i].v0.x, t + 15 * i, 60); triangles[i].isCulled = false; }
         scene_dirty = true;
     }
-    // Update(): camera matrix + the cull pass (rasteriser.cpp:375-447); the clear (:183-192) happens inside Draw()
+    // LoadSTL::LoadSTLFile (LoadSTL.cpp:17-81), the CUSTOM_MODEL branch of main() (rasteriser.cpp:106-110)
+    void LoadSTLFile(const char *path = "Source/enemy1.stl")
+    {
+        const float colour[3] = { 0.5f, 0.5f, 0.5f };
+        const int n = mirt_scene_load_stl(path, 0.05f, colour, nullptr, 0);
+        check(n < 0 ? n : MIRT_OK, "mirt_scene_load_stl");
+        std::vector<float> t((size_t)n * 15);
+        check(std::min(0, mirt_scene_load_stl(path, 0.05f, colour, t.data(), n)), "mirt_scene_load_stl");
+        triangles.resize((size_t)n);
+        for (int i = 0; i < n; i++) { std::memcpy(&triangles[i].v0.x, &t[(size_t)15 * i], 60); triangles[i].isCulled = false; }
+        scene_dirty = true;
+    }
+    // Update(): camera matrix + the cull pass (rasteriser.cpp:375-447); the clear (:183-192) happens inside Draw().
+    // GPU_CULL: the pass runs on the device over the uploaded scene (mirt_cull_device) and only the flags come back.
+    bool GPU_CULL = false;
     void Update()
     {
         update_camera_rot(cameraRot, yaw);
@@ -179,7 +194,16 @@ struct Rasteriser {
         culled.resize(triangles.size());
         const mirt_view view = make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
         const int flags = (BACKFACE_CULLING_ENABLED ? 1 : 0) | (FRUSTUM_CULLING_ENABLED ? 2 : 0);
-        check(mirt_cull(packed.data(), (int)triangles.size(), &view, flags, culled.data()), "mirt_cull");
+        if (GPU_CULL) {
+            if (scene_dirty) {
+                check(mirt_scene_upload(packed.data(), nullptr, (int)triangles.size()), "mirt_scene_upload");
+                scene_dirty = false;
+            }
+            check(mirt_cull_device(&view, flags), "mirt_cull_device");
+            check(mirt_scene_get_culled(culled.data(), (int)culled.size()), "mirt_scene_get_culled");
+        } else {
+            check(mirt_cull(packed.data(), (int)triangles.size(), &view, flags, culled.data()), "mirt_cull");
+        }
         for (size_t i = 0; i < triangles.size(); i++) triangles[i].isCulled = culled[i] != 0;   // :406,412,445
     }
     void Draw()
@@ -187,7 +211,7 @@ struct Rasteriser {
         if (scene_dirty) {
             check(mirt_scene_upload(packed.data(), culled.data(), (int)triangles.size()), "mirt_scene_upload");
             scene_dirty = false;
-        } else {
+        } else if (!GPU_CULL) {                       // with GPU_CULL the flags are already on the device
             check(mirt_scene_set_culled(culled.data(), (int)culled.size()), "mirt_scene_set_culled");
         }
         const mirt_view view = make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);

@@ -20,7 +20,7 @@ KERNEL_NAMES = ("prep", "bin", "trace", "dof", "raster_setup", "raster_frag", "r
 EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
-    "mirt_scene_soup", "mirt_cull", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
+    "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats",
 )
 
@@ -64,6 +64,9 @@ def load():
     lib.mirt_scene_cornell.argtypes = [_vp]
     lib.mirt_scene_soup.argtypes = [C.c_uint32, C.c_int, C.c_float, _vp]
     lib.mirt_cull.argtypes = [_vp, C.c_int, C.POINTER(View), C.c_int, _vp]
+    lib.mirt_cull_device.argtypes = [C.POINTER(View), C.c_int]
+    lib.mirt_scene_get_culled.argtypes = [_vp, C.c_int]
+    lib.mirt_scene_load_stl.argtypes = [C.c_char_p, C.c_float, _vp, _vp, C.c_int]
     lib.mirt_set_soft_shadows.argtypes = [C.c_int, _vp, C.c_int]
     lib.mirt_set_depth_of_field.argtypes = [C.c_int, C.c_float]
     lib.mirt_set_frames_in_flight.argtypes = [C.c_int]
@@ -167,6 +170,29 @@ def cull(tris, view, flags=3):
     c = np.zeros(len(tris), np.uint8)
     _check(load().mirt_cull(_ptr(tris), len(tris), C.byref(view), int(flags), _ptr(c)))
     return c
+
+
+def cull_device(view, flags=3):
+    """The cull step on the GPU for the uploaded scene (flags stay on the device)."""
+    _check(load().mirt_cull_device(C.byref(view), int(flags)))
+
+
+def scene_get_culled():
+    c = np.zeros(load().mirt_scene_size(), np.uint8)
+    _check(load().mirt_scene_get_culled(_ptr(c), len(c)))
+    return c
+
+
+def scene_load_stl(path, scale=0.05, colour=(0.5, 0.5, 0.5)):
+    """LoadSTL::LoadSTLFile: (n, 15) triangles of an ASCII STL, scaled by -scale, one colour, normals recomputed."""
+    col = np.asarray(colour, np.float32)
+    n = load().mirt_scene_load_stl(str(path).encode(), float(scale), _ptr(col), None, 0)
+    if n < 0:
+        raise MirtError("cannot load %s (status %d)" % (path, n))
+    t = np.zeros((n, 15), np.float32)
+    if n:
+        _check(min(0, load().mirt_scene_load_stl(str(path).encode(), float(scale), _ptr(col), _ptr(t), n)))
+    return t
 
 
 def scene_upload(tris, culled=None):

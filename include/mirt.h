@@ -130,6 +130,16 @@ MIRT_API int mirt_scene_soup(uint32_t seed, int n, float s, float *tris15);
 /* The cull step of the rasteriser's Update() (rasteriser.cpp:385-447, InCuboid :451-458), host side.
  * flags: bit0 = BACKFACE_CULLING_ENABLED, bit1 = FRUSTUM_CULLING_ENABLED (both default on, :25-26). */
 MIRT_API int mirt_cull(const float *tris15, int n, const mirt_view *view, int flags, uint8_t *culled);
+/* The same step on the device for the uploaded scene (one thread per triangle; the flags go straight into the scene's
+ * device-side cull array, no host copy either way) -- what replaces the loop at rasteriser.cpp:404-447 once meshes are
+ * large.  mirt_scene_get_culled reads the flags back (the reference's triangles[i].isCulled). */
+MIRT_API int mirt_cull_device(const mirt_view *view, int flags);
+MIRT_API int mirt_scene_get_culled(uint8_t *culled, int n);
+/* LoadSTL::LoadSTLFile (rasteriser/Source/LoadSTL.cpp:17-97): reads an ASCII STL the way the reference does (every line
+ * containing "outer" is followed by three vertex lines), multiplies every coordinate by -scale (the reference: 0.05f),
+ * sets the colour (the reference: 0.5, 0.5, 0.5) and recomputes the normals.  Returns the number of facets in the file;
+ * writes the first max_tris of them when tris15 is not NULL (call with NULL first to size the array). */
+MIRT_API int mirt_scene_load_stl(const char *path, float scale, const float *colour3, float *tris15, int max_tris);
 
 /* Soft shadows (SOFT_SHADOWS_ENABLED / SOFT_SHADOWS_SAMPLES / randomPositions, raytracer.cpp:40-41,84,186-190,
  * 272-287): when samples > 1 every light k is replaced in DirectLight by `samples` jittered positions

@@ -33,6 +33,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -694,4 +695,74 @@ ORACLE_API void mirt_oracle_dof(const float *rgb, const float *fd, int W, int H,
                 }
             out_xrgb[(size_t)y * pitch_words + x] = pack_xrgb(fin);              /* PutPixelSDL :646 */
         }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* LoadSTL::LoadSTLFile + split, rasteriser/Source/LoadSTL.cpp:17-97                            */
+
+/* Reads an ASCII STL as the reference does: every line that contains "outer" (:35) is followed by three vertex lines
+ * (:40-57), each split at single spaces with empty tokens and the token "vertex" dropped (:84-97), the first three tokens
+ * through atof; then every coordinate *= -scale (:63-76; the reference's scale is 0.05f), colour (0.5, 0.5, 0.5) there
+ * (:22), normal by ComputeNormal (:78).  Returns the facet count (-1: cannot open, -2: a vertex line with fewer than
+ * three tokens -- an out-of-range index in the reference).  Writes at most max_tris triangles when tris15 != NULL. */
+ORACLE_API int mirt_oracle_load_stl(const char *path, float scale, const float *colour3, float *tris15, int max_tris)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    int n = 0, c;
+    size_t cap = 256, len;
+    char *line = (char *)malloc(cap);
+    for (;;) {
+        /* std::getline: everything up to the next newline */
+        len = 0;
+        int any = 0;
+        while ((c = fgetc(f)) != EOF) {
+            any = 1;
+            if (c == 10) break;
+            if (len + 2 > cap) { cap *= 2; line = (char *)realloc(line, cap); }
+            line[len++] = (char)c;
+        }
+        if (!any) break;
+        line[len] = 0;
+        if (!strstr(line, "outer")) continue;
+        float v[9];
+        for (int i = 0; i < 3; i++) {
+            len = 0;
+            while ((c = fgetc(f)) != EOF) {
+                if (c == 10) break;
+                if (len + 2 > cap) { cap *= 2; line = (char *)realloc(line, cap); }
+                line[len++] = (char)c;
+            }
+            line[len] = 0;
+            /* split(line, ' '): tokens between single spaces; empty ones and "vertex" are dropped */
+            int nt = 0;
+            char *p = line;
+            for (;;) {
+                char *e = strchr(p, ' ');
+                size_t tl = e ? (size_t)(e - p) : strlen(p);
+                if (tl > 0 && !(tl == 6 && strncmp(p, "vertex", 6) == 0)) {
+                    if (nt < 3) {
+                        char save = p[tl];
+                        p[tl] = 0;
+                        v[3 * i + nt] = (float)atof(p);
+                        p[tl] = save;
+                    }
+                    nt++;
+                }
+                if (!e) break;
+                p = e + 1;
+            }
+            if (nt < 3) { free(line); fclose(f); return -2; }
+        }
+        if (tris15 && n < max_tris) {
+            float *t = tris15 + (size_t)15 * n;
+            for (int k = 0; k < 9; k++) t[k] = v[k] * -scale;
+            t[12] = colour3[0]; t[13] = colour3[1]; t[14] = colour3[2];
+            compute_normal(t);
+        }
+        n++;
+    }
+    free(line);
+    fclose(f);
+    return n;
 }

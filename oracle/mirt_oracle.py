@@ -58,6 +58,8 @@ class Oracle:
         lib.mirt_oracle_rasterise_ex.argtypes = [f32p, _vp, C.c_int, f32p, f32p, C.c_float, C.c_int, C.c_int, _vp,
                                                  C.c_int, f32p, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int]
         lib.mirt_oracle_dof.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int]
+        lib.mirt_oracle_load_stl.argtypes = [C.c_char_p, C.c_float, f32p, _vp, C.c_int]
+        lib.mirt_oracle_load_stl.restype = C.c_int
         for name in ("mat3_inverse", "mat3_mul_vec", "vec_mul_mat3", "normalize", "cross"):
             getattr(lib, "mirt_oracle_" + name).argtypes = [f32p] * (2 if name in ("mat3_inverse", "normalize") else 3)
         lib.mirt_oracle_dot.restype = C.c_float
@@ -80,6 +82,16 @@ class Oracle:
         t = np.zeros((30, 15), np.float32)
         n = self.lib.mirt_oracle_cornell(t)
         assert n == 30
+        return t
+
+    def load_stl(self, path, scale=0.05, colour=(0.5, 0.5, 0.5)):
+        """LoadSTL::LoadSTLFile: the triangles of an ASCII STL, scaled by -scale, grey, normals recomputed."""
+        col = np.asarray(colour, np.float32)
+        n = self.lib.mirt_oracle_load_stl(str(path).encode(), float(scale), col, None, 0)
+        if n < 0:
+            raise ValueError("cannot load %s (code %d)" % (path, n))
+        t = np.zeros((n, 15), np.float32)
+        self.lib.mirt_oracle_load_stl(str(path).encode(), float(scale), col, _ptr(t), n)
         return t
 
     def soup(self, seed, n, s):
