@@ -128,7 +128,7 @@ struct Ctx {
     // staging for the host-buffer entry points
     void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr;
     size_t cap_px = 0;
-    RasterScratch raster;
+    RasterScratch raster[2];                     // one set of rasteriser scratch per stream (frames in flight)
 
     // statistics of the last call
     mirt_stats stats = {};
@@ -745,7 +745,8 @@ extern "C" void mirt_shutdown(void)
                      (void *)g.d_bin_counters, (void *)g.d_entries, (void *)g.d_pair_keys, (void *)g.d_pair_vals, (void *)g.d_sorted_keys, g.d_sort_temp,
                      (void *)g.d_dof_rgb, (void *)g.d_dof_fd, (void *)g.d_dof_xrgb, (void *)g.d_dof_index, (void *)g.d_dof_zinv })
         if (p) (void)hipFree(p);
-    raster_scratch_free(g.raster);
+    raster_scratch_free(g.raster[0]);
+    raster_scratch_free(g.raster[1]);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.ev_chain) (void)hipEventDestroy(g.ev_chain);
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
@@ -933,7 +934,10 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     if (y0 < 0 || y1 > view->height || y0 > y1) return fail(MIRT_ERR_INVALID_ARGUMENT, "row band [%d,%d) outside [0,%d)", y0, y1, view->height);
     if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
 
-    call_begin();
+    // A rasteriser frame touches the scene (read only) and its stream's own scratch, so frames may overlap (call_begin);
+    // with depth of field the planes are the library's own and frames must not.
+    call_begin(d_fd == nullptr);
+    RasterScratch &scratch = g.raster[(g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0];
     g.pending_is_rt = false;
     if (y1 == y0) { call_end(); return MIRT_OK; }
 
@@ -961,9 +965,9 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     f.index = static_cast<int32_t *>(d_index);
     f.fd = static_cast<float *>(d_fd);
     f.focal_plane = g.dof_focal;
-    if ((rc = raster_scratch_ensure(g.raster, g.n, view->width, y1 - y0))) return fail(rc, "raster scratch allocation failed");
+    if ((rc = raster_scratch_ensure(scratch, g.n, view->width, y1 - y0))) return fail(rc, "raster scratch allocation failed");
     if (g.profiling) for (int k = MIRT_K_RASTER_SETUP; k <= MIRT_K_CLEAR; k++) g.ev_used[k] = true;
-    if ((rc = launch_raster(f, g.raster, g.scene_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr)))
+    if ((rc = launch_raster(f, scratch, g.scene_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr)))
         return fail(rc, "rasteriser launch failed: %s", hipGetErrorString(hipGetLastError()));
     call_end();
     return MIRT_OK;
