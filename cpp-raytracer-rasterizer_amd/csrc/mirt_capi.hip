@@ -509,10 +509,11 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     frames[0] = make_camera_frame(view, y0, y1, g.aa);
     nbins = (uint32_t)frames[0].nbu * frames[0].nbv;
     int nframes = 1;
-    // light-cube resolution: 64 bins per face side measured best from 100k to 1M triangles (tools/sweep_cube.sh:
-    // finer grids shorten the shadow lists a little but pay more in binning); MIRT_CUBE_BINS=128|256 overrides
+    // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists and cost more binning; measured
+    // (one light): 100 k triangles 0.37 / 0.47 / 0.92 ms per frame at 64 / 128 / 256, 1 M triangles 5.1 / 3.9 / 4.1 ms.
+    // MIRT_CUBE_BINS=64|128|256 overrides.
     static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
-    int cube_bins = CUBE_BINS_MIN;
+    int cube_bins = g.n >= 300000 ? 2 * CUBE_BINS_MIN : CUBE_BINS_MIN;
     if (cube_override == 64 || cube_override == 128 || cube_override == 256) cube_bins = cube_override;
     RtBinnedFrame bf;
     memset(&bf, 0, sizeof bf);
