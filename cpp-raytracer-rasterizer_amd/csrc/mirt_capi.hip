@@ -561,7 +561,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         return MIRT_OK;
     };
     if (!g.d_entries || !g.cap_entries) {
-        if ((rc = ensure_pairs((size_t)1 << 20))) return rc;
+        // first capacity of the pair list (grown on demand below); MIRT_BIN_INITIAL_PAIRS lets a test start small
+        static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
+        if ((rc = ensure_pairs(initial))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(g.d_frames, frames, sizeof(BinFrameDesc) * nframes, hipMemcpyHostToDevice, g.stream));
 
