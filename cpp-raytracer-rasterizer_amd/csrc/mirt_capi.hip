@@ -69,6 +69,27 @@ int fail(int code, const char *fmt, ...)
 
 enum { EV_CALL0 = 0, EV_CALL1 = 1, EV_K0 = 2, EV_COUNT = 2 + 2 * 8 };
 
+// What a frame of the brute-force / binned ray-trace paths writes besides the caller's planes: one set per stream, so
+// that two frames in flight never share any of it.
+struct RtScratch {
+    OriginRow *d_cam_tab = nullptr;              // n rows (cam_tab_n)
+    OriginRow *d_light_tab = nullptr;            // light_tab_lights x n rows
+    int cam_tab_n = 0, light_tab_n = 0, light_tab_lights = 0;
+    float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
+    uint32_t *d_flags = nullptr;                 // [0] = unsafe flag
+    // binned ray tracing: frame descriptors, per-bin offsets, the (bin, triangle) pair list and its sorted copy
+    BinFrameDesc *d_frames = nullptr;
+    uint32_t *d_bin_off = nullptr, *d_bin_counters = nullptr;
+    uint32_t *d_entries = nullptr;               // triangle ids ordered by bin (the sorted pair values)
+    uint32_t *d_pair_keys = nullptr, *d_pair_vals = nullptr, *d_sorted_keys = nullptr;   // unsorted pairs, sorted bin ids
+    void *d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    uint32_t cap_bins = 0, cap_entries = 0;
+    uint64_t bin_key = 0;
+    uint32_t bin_entries = 0;                    // pairs of the current binning
+    bool bin_key_valid = false;
+};
+
 struct Ctx {
     bool init = false;
     bool profiling = false;
@@ -88,11 +109,7 @@ struct Ctx {
     int n = 0;
     float *d_tris = nullptr;
     uint8_t *d_culled = nullptr;
-    OriginRow *d_cam_tab = nullptr;
-    OriginRow *d_light_tab = nullptr;
-    int light_tab_lights = 0;
-    float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
-    uint32_t *d_flags = nullptr;                 // [0] = unsafe flag
+    RtScratch rt[2];                             // per-stream tables of the non-tile ray-trace paths (frames in flight)
     unsigned long long *d_hits = nullptr;        // the hit-counter buffer of the current frame (one of d_hits2)
     unsigned long long *d_hits2[4] = { nullptr, nullptr, nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
     bool hits_clean[4] = { false, false, false, false };   // buffer is all zero (the tile kernel clears the one two frames ahead itself)
@@ -112,18 +129,6 @@ struct Ctx {
     size_t dof_cap_px = 0;
     int soft_npos = 0;
     float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
-
-    // binned ray tracing: frame descriptors, per-bin offsets / cursors, candidate entries
-    BinFrameDesc *d_frames = nullptr;
-    uint32_t *d_bin_off = nullptr, *d_bin_counters = nullptr;
-    uint32_t *d_entries = nullptr;               // triangle ids ordered by bin (the sorted pair values)
-    uint32_t *d_pair_keys = nullptr, *d_pair_vals = nullptr, *d_sorted_keys = nullptr;   // unsorted pairs, sorted bin ids
-    void *d_sort_temp = nullptr;
-    size_t sort_temp_bytes = 0;
-    uint32_t cap_bins = 0, cap_entries = 0;
-    uint64_t bin_key = 0;
-    uint32_t bin_entries = 0;                    // candidate-list entries of the current binning
-    bool bin_key_valid = false;
 
     // staging for the host-buffer entry points
     void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr;
@@ -310,18 +315,11 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     const int light_positions = nlights * (g.soft_samples > 1 ? g.soft_samples : 1);    // shadow-ray origins
     if (light_positions > MIRT_MAX_LIGHTS)
         return fail(MIRT_ERR_INVALID_ARGUMENT, "%d lights x %d soft-shadow samples exceed %d light positions", nlights, g.soft_samples, MIRT_MAX_LIGHTS);
-    if (light_positions > g.light_tab_lights) {
-        if ((rc = dev_realloc(&g.d_light_tab, (size_t)light_positions * g.n))) { g.light_tab_lights = 0; return rc; }
-        g.light_tab_lights = light_positions;
-    }
 
     RtFrame f;
     memset(&f, 0, sizeof f);
     f.tris15 = g.d_tris;
     f.n = g.n;
-    f.cam_tab = g.d_cam_tab;
-    f.light_tab = g.d_light_tab;
-    f.unsafe = g.d_flags;
     memcpy(f.cam, view->pos, sizeof f.cam);
     memcpy(f.rot, view->rot, sizeof f.rot);
     f.focal = view->focal;
@@ -384,9 +382,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     const size_t tile_lds = (size_t)g.n * 16 * (12 + 3 * nlights);
     const bool tile_path = !binned && safe && tile_w && g.n <= 64 && tile_lds <= 64 * 1024;
 
-    // The tile kernel reads only the scene and writes only the caller's planes and its own hit counters, so frames
-    // of it may overlap (call_begin); with depth of field the planes are the library's own and frames must not.
-    call_begin(tile_path && d_fd == nullptr);
+    // A frame reads the scene and writes the caller's planes plus its stream's own tables and counters, so frames may
+    // overlap (call_begin); with depth of field the planes are the library's own and frames must not.
+    call_begin(d_fd == nullptr);
     g.pending_is_rt = true;
     g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0) * (uint64_t)((g.aa > 1 ? g.aa : 1) * (g.aa > 1 ? g.aa : 1));
     g.pending_nlights = light_positions;
@@ -396,13 +394,30 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     if (y1 == y0) { call_end(); return MIRT_OK; }
     // hit counters: every stream owns two buffers used alternately, so that a kernel can clear the one the NEXT frame
     // on its stream will use
-    {
-        const int si = (g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0;
-        g.hits_tog[si] ^= 1;
-        g.hits_cur = si + 2 * g.hits_tog[si];
-    }
+    const int si = (g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0;
+    g.hits_tog[si] ^= 1;
+    g.hits_cur = si + 2 * g.hits_tog[si];
     g.d_hits = g.d_hits2[g.hits_cur];
     f.hit_count = g.d_hits;
+    RtScratch &S = g.rt[si];
+    if (!tile_path) {                            // origin tables of this stream, sized for the scene and the light positions
+        if (S.cam_tab_n != g.n) {
+            S.cam_tab_n = 0;
+            if ((rc = dev_realloc(&S.d_cam_tab, (size_t)g.n))) return rc;
+            S.cam_tab_n = g.n;
+        }
+        if (light_positions > S.light_tab_lights || S.light_tab_n != g.n) {
+            S.light_tab_lights = 0;
+            if ((rc = dev_realloc(&S.d_light_tab, (size_t)light_positions * g.n))) return rc;
+            S.light_tab_lights = light_positions;
+            S.light_tab_n = g.n;
+        }
+        if (!S.d_origins) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
+        if (!S.d_flags) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_flags), 16)); HIP_TRY(hipMemset(S.d_flags, 0, 16)); }
+    }
+    f.cam_tab = S.d_cam_tab;
+    f.light_tab = S.d_light_tab;
+    f.unsafe = S.d_flags;
 
     if (tile_path) {
         RtTileFrame tf;
@@ -468,14 +483,14 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         return MIRT_OK;
     }
 
-    HIP_TRY(hipMemcpyAsync(g.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(S.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
     g.hits_clean[g.hits_cur] = false;
-    HIP_TRY(hipMemcpyAsync(g.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
 
     k_begin(MIRT_K_PREP);
     hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1 + nlights), dim3(256), 0, g.stream,
-                       g.d_tris, g.n, g.d_origins, g.d_cam_tab, g.d_light_tab, g.d_flags);
+                       g.d_tris, g.n, S.d_origins, S.d_cam_tab, S.d_light_tab, S.d_flags);
     k_end(MIRT_K_PREP);
 
     if (!binned && g.aa <= 1 && (long long)view->width * rows <= 4096 && g.n >= 1024) {
@@ -535,37 +550,37 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             nbins += (uint32_t)(cube_bins * cube_bins);
         }
     }
-    if (nbins + 1 > g.cap_bins) {
+    if (nbins + 1 > S.cap_bins) {
         const size_t cap = (size_t)nbins + 1;
-        if ((rc = dev_realloc(&g.d_bin_off, cap))) { g.cap_bins = 0; return rc; }
-        g.cap_bins = (uint32_t)cap;
-        g.bin_key_valid = false;
+        if ((rc = dev_realloc(&S.d_bin_off, cap))) { S.cap_bins = 0; return rc; }
+        S.cap_bins = (uint32_t)cap;
+        S.bin_key_valid = false;
     }
-    if (!g.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_frames), sizeof(BinFrameDesc) * MAX_BIN_FRAMES));
-    if (!g.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_bin_counters), 64)); HIP_TRY(hipMemset(g.d_bin_counters, 0, 64)); }
+    if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * MAX_BIN_FRAMES));
+    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 64)); HIP_TRY(hipMemset(S.d_bin_counters, 0, 64)); }
     int key_bits = 1;
     while ((1u << key_bits) < nbins && key_bits < 32) key_bits++;
     auto ensure_pairs = [&](size_t cap) -> int {           // pair list, its sorted copy and the sort's scratch, all for `cap` pairs
         int r;
-        if ((r = dev_realloc(&g.d_entries, cap)) || (r = dev_realloc(&g.d_pair_keys, cap)) || (r = dev_realloc(&g.d_pair_vals, cap)) ||
-            (r = dev_realloc(&g.d_sorted_keys, cap))) { g.cap_entries = 0; return r; }
+        if ((r = dev_realloc(&S.d_entries, cap)) || (r = dev_realloc(&S.d_pair_keys, cap)) || (r = dev_realloc(&S.d_pair_vals, cap)) ||
+            (r = dev_realloc(&S.d_sorted_keys, cap))) { S.cap_entries = 0; return r; }
         const size_t need = bin_sort_temp_bytes((uint32_t)cap, 32);
         if (need == 0) return fail(MIRT_ERR_HIP, "radix sort: cannot size its temporary storage for %zu pairs", cap);
-        if (need > g.sort_temp_bytes) {
-            if (g.d_sort_temp) (void)hipFree(g.d_sort_temp);
-            g.d_sort_temp = nullptr; g.sort_temp_bytes = 0;
-            if (hipMalloc(&g.d_sort_temp, need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "radix sort scratch (%zu bytes)", need);
-            g.sort_temp_bytes = need;
+        if (need > S.sort_temp_bytes) {
+            if (S.d_sort_temp) (void)hipFree(S.d_sort_temp);
+            S.d_sort_temp = nullptr; S.sort_temp_bytes = 0;
+            if (hipMalloc(&S.d_sort_temp, need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "radix sort scratch (%zu bytes)", need);
+            S.sort_temp_bytes = need;
         }
-        g.cap_entries = (uint32_t)cap;
+        S.cap_entries = (uint32_t)cap;
         return MIRT_OK;
     };
-    if (!g.d_entries || !g.cap_entries) {
+    if (!S.d_entries || !S.cap_entries) {
         // first capacity of the pair list (grown on demand below); MIRT_BIN_INITIAL_PAIRS lets a test start small
         static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
         if ((rc = ensure_pairs(initial))) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(g.d_frames, frames, sizeof(BinFrameDesc) * nframes, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(S.d_frames, frames, sizeof(BinFrameDesc) * nframes, hipMemcpyHostToDevice, g.stream));
 
     // persistent workgroups over the (256-triangle chunk, frame) work items: 3 per CU (52 KiB of LDS each)
     const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + 255) / 256) * nframes, (long long)g.cu_count * 3));
@@ -577,41 +592,41 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     }
 
     BinSet bs;
-    bs.frames = g.d_frames; bs.nframes = nframes; bs.nbins = nbins;
-    bs.bin_off = g.d_bin_off; bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
-    bs.counters = g.d_bin_counters;
+    bs.frames = S.d_frames; bs.nframes = nframes; bs.nbins = nbins;
+    bs.bin_off = S.d_bin_off; bs.entries = S.d_entries; bs.cap_entries = S.cap_entries;
+    bs.counters = S.d_bin_counters;
     k_begin(MIRT_K_BIN);
     // The pair list is sized from a count only the device knows; it is read back (4 bytes + one sync) only when the
     // inputs that determine it changed since the last frame, and the pass is repeated if the list was too small.
-    const bool fresh = !g.bin_key_valid || g.bin_key != key;
+    const bool fresh = !S.bin_key_valid || S.bin_key != key;
     for (int attempt = 0; attempt < 2; attempt++) {
-        BinPairs pairs = { g.d_pair_keys, g.d_pair_vals, g.cap_entries };
-        HIP_TRY(hipMemsetAsync(g.d_bin_counters, 0, 4, g.stream));
-        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(256), 0, g.stream, g.d_tris, g.d_cam_tab, g.d_light_tab, g.n, bs, pairs);
+        BinPairs pairs = { S.d_pair_keys, S.d_pair_vals, S.cap_entries };
+        HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 4, g.stream));
+        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(256), 0, g.stream, g.d_tris, S.d_cam_tab, S.d_light_tab, g.n, bs, pairs);
         if (!fresh) break;
         uint32_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, g.d_bin_counters, 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(&total, S.d_bin_counters, 4, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        g.bin_entries = total;
-        if (total <= g.cap_entries) break;
-        if (attempt == 1) return fail(MIRT_ERR_HIP, "binning produced %u pairs twice with room for %u", total, g.cap_entries);
+        S.bin_entries = total;
+        if (total <= S.cap_entries) break;
+        if (attempt == 1) return fail(MIRT_ERR_HIP, "binning produced %u pairs twice with room for %u", total, S.cap_entries);
         if ((rc = ensure_pairs((size_t)total + total / 8 + 4096))) return rc;
-        bs.entries = g.d_entries; bs.cap_entries = g.cap_entries;
+        bs.entries = S.d_entries; bs.cap_entries = S.cap_entries;
     }
 #ifdef MIRT_BIN_STATS
     if (fresh) {
         uint32_t c[16];
-        (void)hipMemcpy(c, g.d_bin_counters, 64, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(c, S.d_bin_counters, 64, hipMemcpyDeviceToHost);
         fprintf(stderr, "[mirt bin stats] flattened tests=%u max per work item=%u direct items=%u | huge: box valid=%u no box=%u (camera frame %u)\n", c[8], c[9], c[10], c[11], c[12], c[14]);
         fprintf(stderr, "[mirt bin stats] tris=%d frames=%d  pairs=%u  bins=%u | large items walked=%u level-1 rounds=%u level-2 steps=%u pairs=%u max steps/item=%u items>100 steps=%u\n",
-                g.n, nframes, g.bin_entries, nbins, c[2], c[3], c[4], c[5], c[6], c[7]);
-        (void)hipMemset(g.d_bin_counters + 2, 0, 56);
+                g.n, nframes, S.bin_entries, nbins, c[2], c[3], c[4], c[5], c[6], c[7]);
+        (void)hipMemset(S.d_bin_counters + 2, 0, 56);
     }
 #endif
-    g.bin_key = key;
-    g.bin_key_valid = true;
-    HIP_TRY(bin_sort_pairs(g.d_sort_temp, g.sort_temp_bytes, g.d_pair_keys, g.d_sorted_keys, g.d_pair_vals, g.d_entries, g.bin_entries, key_bits, g.stream));
-    hipLaunchKernelGGL(k_bin_offsets, dim3((nbins + 1 + 255) / 256), dim3(256), 0, g.stream, g.d_sorted_keys, g.d_bin_counters, g.cap_entries, nbins, g.d_bin_off);
+    S.bin_key = key;
+    S.bin_key_valid = true;
+    HIP_TRY(bin_sort_pairs(S.d_sort_temp, S.sort_temp_bytes, S.d_pair_keys, S.d_sorted_keys, S.d_pair_vals, S.d_entries, S.bin_entries, key_bits, g.stream));
+    hipLaunchKernelGGL(k_bin_offsets, dim3((nbins + 1 + 255) / 256), dim3(256), 0, g.stream, S.d_sorted_keys, S.d_bin_counters, S.cap_entries, nbins, S.d_bin_off);
     k_end(MIRT_K_BIN);
 
     bf.f = f;
@@ -723,9 +738,6 @@ extern "C" int mirt_init(int device)
     g.last_self_contained = false;
     HIP_TRY(hipEventCreateWithFlags(&g.ev_chain, hipEventDisableTiming));
     for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev[i]));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_flags), 16));
-    HIP_TRY(hipMemset(g.d_flags, 0, 16));
     for (int i = 0; i < 4; i++) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits2[i]), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
         HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
@@ -743,9 +755,11 @@ extern "C" void mirt_shutdown(void)
     if (!g.init) return;
     (void)hipSetDevice(g.device);
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
-    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_cam_tab, (void *)g.d_light_tab, (void *)g.d_origins,
-                     (void *)g.d_flags, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, (void *)g.d_frames, (void *)g.d_bin_off,
-                     (void *)g.d_bin_counters, (void *)g.d_entries, (void *)g.d_pair_keys, (void *)g.d_pair_vals, (void *)g.d_sorted_keys, g.d_sort_temp,
+    for (RtScratch &S : g.rt)
+        for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_bin_off,
+                         (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp })
+            if (p) (void)hipFree(p);
+    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv,
                      (void *)g.d_dof_rgb, (void *)g.d_dof_fd, (void *)g.d_dof_xrgb, (void *)g.d_dof_index, (void *)g.d_dof_zinv })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster[0]);
@@ -798,9 +812,7 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     g.n = 0;
     if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
     if ((rc = dev_realloc(&g.d_culled, (size_t)n))) return rc;
-    if ((rc = dev_realloc(&g.d_cam_tab, (size_t)n))) return rc;
-    if ((rc = dev_realloc(&g.d_light_tab, (size_t)0))) return rc;
-    g.light_tab_lights = 0;
+    for (RtScratch &S : g.rt) S.bin_key_valid = false;      // the origin tables are re-sized by the next frame that needs them
     HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
     if (culled) HIP_TRY(hipMemcpy(g.d_culled, culled, (size_t)n, hipMemcpyHostToDevice));
     else HIP_TRY(hipMemset(g.d_culled, 0, (size_t)n));
