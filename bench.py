@@ -71,6 +71,19 @@ def measured_traffic(workload, kernel_prefixes):
     return tot or None
 
 
+def measured_valu_instructions(workload, kernel_prefix):
+    """Wave-level VALU instructions per launch of the named kernel from the committed rocprofv3 PMC pass
+    (profiles/r01_pmc_issue_<workload>.txt, SQ_INSTS_VALU averaged over the launches), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_issue_%s.txt" % workload)) as f:
+            for line in f:
+                if line.startswith("pmc1") and kernel_prefix in line and "SQ_INSTS_VALU" in line:
+                    return float(line.split("'SQ_INSTS_VALU':")[1].split(",")[0].strip(" }\n"))
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, samples=1, jitter=None, aa=1):
     """The oracle (CPU restatement, oracle/mirt_oracle.c) timed on this host's cores on a bounded sample of
     the same workload.  Test infrastructure: measured as a baseline, never used by the product path."""
@@ -297,6 +310,14 @@ def main():
                                        "parity forbids FMA contraction, so the reachable ceiling is 1/2 of peak. achieved = tests the "
                                        "launch EXECUTED x 60 flop; reference_equivalent = the brute-force work of the reference "
                                        "(rays x triangles x 60) over the same time"}
+            insts = measured_valu_instructions(args.workload, kname) if world == 1 else None
+            if insts and kt > 0:
+                # issue-slot view of the same kernel: VALU instructions per launch (profiled) over the live duration, per SIMD
+                # and clock, against the measured issue ceiling of gfx950 (profiles/r01_ubench_valu_lds.txt: 0.24 / clk / SIMD)
+                ipc = insts / (kt * 1e-3 * 2.4e9 * 1024)
+                out["roofline"]["valu_issue"] = {"instructions_per_launch": int(insts), "achieved": round(ipc, 4), "peak": 0.24,
+                                                 "unit": "wave-instr/clk/SIMD", "frac": round(ipc / 0.24, 4),
+                                                 "source": "profiles/r01_pmc_issue_%s.txt (SQ_INSTS_VALU)" % args.workload}
             algo_bytes = 4.0 * W * (y1 - y0) + 60.0 * len(tris)
             if kt > 0:
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": round(algo_bytes / (kt * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
