@@ -16,4 +16,5 @@ done
 tools/pmc_valu.sh cornell1080 --workload cornell1080 --steps 50 --warmup 5 > gpurun_out/pmcv_cornell1080.txt 2>&1
 tools/pmc_valu.sh raster4kdof8 --workload raster4kdof8 --steps 20 --warmup 2 > gpurun_out/pmcv_raster4kdof8.txt 2>&1
 tools/ubench > gpurun_out/ubench.txt 2>&1
+tools/sortbench > gpurun_out/sortbench.txt 2>&1
 echo done

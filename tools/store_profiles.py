@@ -29,4 +29,6 @@ for t in ("cornell1080", "raster4kdof8"):
         open("profiles/%s_pmc_issue_%s.txt" % (tag, t), "w").writelines(keep)
 if os.path.exists("gpurun_out/ubench.txt") and os.path.getsize("gpurun_out/ubench.txt") > 0:
     shutil.copy("gpurun_out/ubench.txt", "profiles/%s_ubench_valu_lds.txt" % tag)
+if os.path.exists("gpurun_out/sortbench.txt") and os.path.getsize("gpurun_out/sortbench.txt") > 0:
+    shutil.copy("gpurun_out/sortbench.txt", "profiles/%s_sortbench.txt" % tag)
 print(sorted(os.listdir("profiles")))
