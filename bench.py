@@ -14,7 +14,9 @@ Prints ONE JSON line (rank 0).  Workloads (BASELINE.json `configs`):
     cornell1080dof8, raster4kdof8   configs[1] / configs[3] with the 8x8 depth-of-field blur
     soup1m8k     (configs[4]) 1M random triangles, 7680x4320 (meant for 8 GPUs)
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the frame is split into N bands of
-rows; every rank renders its band and the XRGB bands are gathered on rank 0 over RCCL ("scaling": "strong").
+rows; every rank renders its band and the XRGB bands are gathered on rank 0 over RCCL ("scaling": "strong"); frames
+that render in microseconds travel 32 to a gather.  MIRT_BENCH_REHEARSAL=1 runs that control flow with every rank on
+device 0 (gloo, host-staged gathers) and checks the assembled frames against a single-GPU frame -- not a measurement.
 """
 import argparse
 import json
@@ -152,10 +154,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
+    # MIRT_BENCH_REHEARSAL=1: every rank on device 0 with a gloo group and host-staged gathers -- the N > 1 control flow
+    # (batches, events, reductions) on a one-GPU box.  Not a measurement.
+    rehearsal = world > 1 and os.environ.get("MIRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     mirt.init(local_rank)
 
     kind, scene, W, H, cam, focal, rot11 = WORKLOADS[args.workload]
@@ -183,41 +193,65 @@ def main():
     from mirt.sharding import BandGather
     dev = torch.device("cuda", local_rank)
     depth = 2
-    bands = BandGather(H, W, dev, depth=depth)  # this rank's two XRGB bands (+ the gathered frame on rank 0)
+    # Several GPUs: frames that render faster than a collective starts (the 30-triangle scenes: ~25 us per frame, a band of
+    # it a few us) travel `batch` at a time -- one RCCL gather moves the bands of 32 consecutive frames; heavy frames (the
+    # soups: milliseconds) go one per gather.  Every frame is still rendered, gathered and assembled inside the timed region.
+    batch = 32 if (world > 1 and len(tris) < 1000) else 1
+    bands = BandGather(H, W, dev, depth=depth, batch=batch, via_host=rehearsal)  # this rank's two band buffers (+ the gathered frames on rank 0)
     y0, y1 = bands.y0, bands.y1
     # One GPU: two frames in flight, alternating between the two bands (the library alternates between two streams, so
     # the next frame is dispatched while the previous one drains).  Several GPUs: one frame in flight per rank, the
-    # RCCL gather of the previous frame overlaps it instead.
+    # RCCL gather of the previous batch overlaps it instead.
     mirt.set_frames_in_flight(2 if world == 1 else 1)
     mirt_stream = torch.cuda.ExternalStream(mirt.load().mirt_stream(), device=dev)
-    renders = []
-    for b in bands.bands_buf:
-        if kind == "rt":
-            renders.append(mirt.prepared_raytrace_device(view, LIGHT, INDIRECT, mode, y0, y1, y0, b.data_ptr(), W * 4))
-        else:
-            renders.append(mirt.prepared_rasterise_device(view, LIGHT, INDIRECT, y0, y1, y0, b.data_ptr(), W * 4))
-    render = renders[0]
+    renders = []                                   # renders[k][b]: enqueue one frame into slot b of band buffer k
+    for k in range(depth):
+        row = []
+        for b in range(batch):
+            ptr = bands.slot(k, b).data_ptr()
+            if kind == "rt":
+                row.append(mirt.prepared_raytrace_device(view, LIGHT, INDIRECT, mode, y0, y1, y0, ptr, W * 4))
+            else:
+                row.append(mirt.prepared_rasterise_device(view, LIGHT, INDIRECT, y0, y1, y0, ptr, W * 4))
+        renders.append(row)
+    render = renders[0][0]
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    rendered = [torch.cuda.Event() for _ in range(depth)]      # band k holds a finished frame
-    gathered = [torch.cuda.Event() for _ in range(depth)]      # band k has been sent and may be overwritten
+    rendered = [torch.cuda.Event() for _ in range(depth)]      # band buffer k holds a finished batch
+    gathered = [torch.cuda.Event() for _ in range(depth)]      # band buffer k has been sent and may be overwritten
     frame_no = [0]
 
-    def step():
-        if world == 1:
-            renders[frame_no[0] & 1]()
-            frame_no[0] += 1
-            return
-        # Double-buffered bands: frame i renders into band i%2 on mirt's stream while the RCCL gather of frame i-1
-        # (the other band) is still in flight on the communication stream.  Dependencies are two events per band.
-        k = frame_no[0] % depth
-        frame_no[0] += 1
-        mirt_stream.wait_event(gathered[k])                    # the gather that last read band k has finished
-        renders[k]()
+    def flush(k):
+        """The batch in band buffer k is complete: gather it on the communication stream."""
         rendered[k].record(mirt_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(rendered[k])
             bands.gather(k)
             gathered[k].record(comm_stream)
+
+    def step():
+        i = frame_no[0]
+        frame_no[0] += 1
+        if world == 1:
+            renders[i & 1][0]()
+            return
+        # Double-buffered band buffers: batch j renders into buffer j%2 on mirt's stream while the RCCL gather of batch
+        # j-1 (the other buffer) is still in flight on the communication stream.  Dependencies are two events per buffer.
+        b, k = i % batch, (i // batch) % depth
+        if b == 0:
+            mirt_stream.wait_event(gathered[k])                # the gather that last read buffer k has finished
+        renders[k][b]()
+        if b == batch - 1:
+            flush(k)
+
+    last_batch = [batch]                             # frames the most recent gather carried
+
+    def finish_batch():
+        """Gathers a batch the loop left incomplete and restarts the batch numbering."""
+        last_batch[0] = batch
+        if world > 1 and frame_no[0] % batch:
+            last_batch[0] = frame_no[0] % batch
+            flush((frame_no[0] // batch) % depth)
+        frame_no[0] = 0
 
     def fence():
         mirt.sync()
@@ -230,6 +264,7 @@ def main():
 
     for _ in range(warmup):
         step()
+    finish_batch()
     fence()
     st = mirt.stats()
     t0 = time.perf_counter()
@@ -238,6 +273,7 @@ def main():
         ev0.record(mirt_stream)
     for _ in range(steps):
         step()
+    finish_batch()
     if world > 1:
         ev1.record(mirt_stream)
     fence()
@@ -246,15 +282,31 @@ def main():
     # frames alternate between two streams and the wall clock between the fences is the measure)
     gpu_total_ms = ev0.elapsed_time(ev1) if world > 1 else dt * 1e3
 
+    if rehearsal and rank == 0:
+        # the frames rank 0 assembled from every rank's bands against one full-frame render (interior words; the border
+        # is never written by the ray tracer)
+        full = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        if kind == "rt":
+            mirt.raytrace_device(view, LIGHT, INDIRECT, mode, 0, H, 0, full.data_ptr(), W * 4)
+        else:
+            mirt.rasterise_device(view, LIGHT, INDIRECT, 0, H, 0, full.data_ptr(), W * 4)
+        mirt.sync()
+        got = bands.frames[: last_batch[0]] if batch > 1 else bands.frame.unsqueeze(0)
+        same = all(bool(torch.equal(got[b], full)) for b in range(got.shape[0]))
+        print("rehearsal: %d gathered frame(s) identical to the single-GPU frame: %s" % (got.shape[0], same), file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit("rehearsal: gathered frames differ from the single-GPU frame")
+
     # whole-job numbers: MAX over ranks of the wall time, SUM over ranks of the rays
     st = mirt.stats()
     rays_rank = float(st["primary_rays"] + st["shadow_rays"]) if kind == "rt" else 0.0
     tests_rank = float(st["tests"])
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if rehearsal else dev
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([rays_rank, tests_rank, float(st["shadow_rays"])], dtype=torch.float64, device=dev)
+        s = torch.tensor([rays_rank, tests_rank, float(st["shadow_rays"])], dtype=torch.float64, device=rdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         rays_frame, tests_frame, shadow_frame = [float(x) for x in s.tolist()]
     else:
@@ -290,7 +342,7 @@ def main():
                 "config": {"workload": args.workload, "scene": "cornell-30" if scene[0] == "cornell" else "soup-%d-seed%d" % (scene[2], scene[1]),
                            "triangles": int(len(tris)), "width": W, "height": H, "lights": 1, "soft_shadow_samples": soft_samples, "aa_samples": aa, "dof_kernel": dof,
                            "primary_rays": W * H * aa * aa, "shadow_rays": int(shadow_frame), "mode": ["auto", "brute", "binned"][st["mode_used"]],
-                           "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
+                           "parallelism": ("bands%d+gather" % world + ("x%d" % batch if batch > 1 else "")) if world > 1 else "1gpu"},
             })
             kt = kernel_ms.get("trace", 0.0)
             kname = {mirt.RT_BRUTE: ("k_rt_tile<" if aa > 1 else "k_rt_tile2") if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),

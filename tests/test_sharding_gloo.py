@@ -57,3 +57,45 @@ def test_band_of_partitions_rows():
             assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in bands]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_batched(rank, world, port, W, H, batch, out_path):
+    for sub in ("oracle", "cpp-raytracer-rasterizer_amd"):
+        sys.path.insert(0, os.path.join(ROOT, sub))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirt.sharding import BandGather
+    from mirt_oracle import Oracle, DEFAULT_LIGHT
+    o = Oracle()
+    tris = o.cornell()
+    g = BandGather(H, W, torch.device("cpu"), depth=2, batch=batch)
+    for which in (0, 1):                                   # both band buffers, every frame of a batch from another camera yaw
+        for b in range(batch):
+            rot = o.rot_from_yaw(0.1 * (b + 1) + which, 1.0)
+            r = o.raytrace(tris, (0, 0, -2), rot, H / 2.0, W, H, DEFAULT_LIGHT, y0=g.y0, y1=g.y1, threads=2, want=("xrgb",))
+            g.slot(which, b)[: g.y1 - g.y0] = torch.from_numpy(r["xrgb"][g.y0:g.y1].view(np.int32))
+        g.gather(which)
+        if rank == 0:
+            np.save(out_path % which, g.frames.numpy().view(np.uint32).copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,batch", [(2, 40, 3), (3, 31, 4)])
+def test_batched_band_gather(tmp_path, oracle, world, H, batch):
+    """Several frames' bands per collective (what bench.py does for frames that render faster than a collective starts):
+    every frame of the batch must come out whole, for even and uneven bands and for both band buffers."""
+    from mirt_oracle import DEFAULT_LIGHT
+    W = 40
+    out = str(tmp_path / "frames%d.npy")
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker_batched, args=(world, port, W, H, batch, out), nprocs=world, join=True)
+    tris = oracle.cornell()
+    for which in (0, 1):
+        got = np.load(out % which)
+        assert got.shape == (batch, H, W)
+        for b in range(batch):
+            rot = oracle.rot_from_yaw(0.1 * (b + 1) + which, 1.0)
+            ref = oracle.raytrace(tris, (0, 0, -2), rot, H / 2.0, W, H, DEFAULT_LIGHT, want=("xrgb",))["xrgb"]
+            assert np.array_equal(got[b], ref)
