@@ -650,3 +650,61 @@ def test_rt_binned_pair_list_grows(oracle, tmp_path):
         mirt.init(0)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().endswith("OK"), out.stdout[-500:]
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_rt_binned_equals_brute_on_random_configurations(oracle, seed):
+    """Seeded random scenes, cameras (some inside the soup, some rotated past 90 degrees) and one to three lights (some
+    inside the soup, some almost in a triangle's plane): the binned frame -- conservative boxes, behind-the-plane rule,
+    flattened bin tests, sorted pair lists -- must equal the brute-force frame word for word, plane for plane.  (Brute
+    force itself is checked against the oracle above; this widens the binner's coverage cheaply.)"""
+    rng = np.random.RandomState(1000 + seed)
+    n = int(rng.choice([600, 1500, 4000, 9000]))
+    size = float(rng.choice([0.03, 0.08, 0.2, 0.5]))
+    tris = mirt.scene_soup(200 + seed, n, size)
+    if seed % 4 == 0:
+        tris = np.concatenate([tris, mirt.scene_cornell()])             # walls: the wave-walk path, exact ties
+    W, H = int(rng.randint(90, 420)), int(rng.randint(70, 300))
+    cam = rng.uniform(-1.2, 1.2, 3) if seed % 3 == 0 else np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), -rng.uniform(1.5, 3.0)])
+    rot = oracle.rot_from_yaw(float(rng.uniform(-3.1, 3.1)) if seed % 2 else float(rng.uniform(-0.4, 0.4)), 1.0)
+    focal = float(rng.uniform(0.3, 1.2) * H)
+    nl = 1 + seed % 3
+    lights = np.zeros((nl, 7), np.float32)
+    lights[:, 0:3] = rng.uniform(-0.9, 0.9, (nl, 3))
+    lights[:, 3:6] = rng.uniform(0.2, 1.0, (nl, 3))
+    lights[:, 6] = rng.uniform(3, 20, nl)
+    if seed % 5 == 0:                                                   # a light (almost) in the plane of triangle 7
+        v0, e1, e2 = tris[7, 0:3], tris[7, 3:6] - tris[7, 0:3], tris[7, 6:9] - tris[7, 0:3]
+        lights[0, 0:3] = v0 + 3.0 * e1 - 2.5 * e2 + (1e-7 if seed % 10 == 0 else 0.0) * tris[7, 9:12]
+    mirt.scene_upload(tris)
+    view = mirt.make_view(cam, rot, focal, W, H)
+    a = mirt.raytrace(view, lights, mode=mirt.RT_BINNED)
+    b = mirt.raytrace(view, lights, mode=mirt.RT_BRUTE)
+    assert a["stats"]["mode_used"] == mirt.RT_BINNED and b["stats"]["mode_used"] == mirt.RT_BRUTE
+    assert np.array_equal(a["index"], b["index"]), "closest-hit index differs in %d pixels" % int((a["index"] != b["index"]).sum())
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert np.array_equal(a["xrgb"], b["xrgb"])
+    assert a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_rt_tile_kernel_on_random_small_scenes(oracle, seed):
+    """Scenes of 1 to 64 triangles take the two-pixels-per-lane tile kernel (packed FP32, candidate masks, DPP direction
+    boxes).  Seeded random triangles (large ones, so tiles see many candidates), cameras, lights and ragged frame sizes,
+    sometimes with soft shadows: index, float colours and surface against the oracle."""
+    rng = np.random.RandomState(5000 + seed)
+    n = int(rng.choice([1, 2, 7, 30, 63, 64]))
+    tris = mirt.scene_soup(900 + seed, n, float(rng.choice([0.3, 0.8, 1.5])))
+    W, H = int(rng.randint(17, 200)), int(rng.randint(9, 150))
+    cam = np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6), -rng.uniform(0.5, 3.0)])
+    rot = oracle.rot_from_yaw(float(rng.uniform(-0.8, 0.8)), 1.0)
+    nl = 1 + seed % 2
+    lights = np.zeros((nl, 7), np.float32)
+    lights[:, 0:3] = rng.uniform(-1.0, 1.0, (nl, 3))
+    lights[:, 3:6] = rng.uniform(0.2, 1.0, (nl, 3))
+    lights[:, 6] = rng.uniform(3, 20, nl)
+    samples = 4 if seed % 6 == 0 else 1
+    jit = _jitter(oracle, lights, samples, seed=seed + 1) if samples > 1 else None
+    got, _ = _rt_compare(oracle, tris, cam, rot, float(rng.uniform(0.4, 1.1) * H), W, H, lights, mode=mirt.RT_AUTO, threads=8,
+                         samples=samples, jitter=jit)
+    assert got["stats"]["mode_used"] == mirt.RT_BRUTE
