@@ -708,3 +708,23 @@ def test_rt_tile_kernel_on_random_small_scenes(oracle, seed):
     got, _ = _rt_compare(oracle, tris, cam, rot, float(rng.uniform(0.4, 1.1) * H), W, H, lights, mode=mirt.RT_AUTO, threads=8,
                          samples=samples, jitter=jit)
     assert got["stats"]["mode_used"] == mirt.RT_BRUTE
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_raster_on_random_configurations(oracle, seed):
+    """Seeded random soups, cameras (rotated, close to and inside the geometry), cull flags and frame sizes through the
+    rasteriser: culled set, owner index, depth, float colours and surface against the oracle."""
+    rng = np.random.RandomState(7000 + seed)
+    n = int(rng.choice([40, 300, 2000]))
+    tris = mirt.scene_soup(300 + seed, n, float(rng.choice([0.05, 0.2, 0.6])))
+    if seed % 3 == 0:
+        tris = np.concatenate([tris, mirt.scene_cornell()])
+    W, H = int(rng.randint(33, 260)), int(rng.randint(20, 200))
+    cam = np.array([rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), -rng.uniform(0.3, 3.5)])
+    rot = oracle.rot_from_yaw(float(rng.uniform(-1.0, 1.0)), 1.01)
+    nl = 1 + seed % 2
+    lights = np.zeros((nl, 7), np.float32)
+    lights[:, 0:3] = rng.uniform(-1.0, 1.0, (nl, 3))
+    lights[:, 3:6] = rng.uniform(0.2, 1.0, (nl, 3))
+    lights[:, 6] = rng.uniform(3, 20, nl)
+    _raster_compare(oracle, tris, cam, rot, float(rng.uniform(0.5, 1.3) * H), W, H, lights, cull_flags=seed % 4)
