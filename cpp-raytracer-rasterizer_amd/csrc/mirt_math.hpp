@@ -90,8 +90,11 @@ MIRT_HD int f2i_x86(float f)
 MIRT_HD uint32_t chan8(float c)
 {
     float v = 255 * c;
-    v = (v > 0.0f) ? v : 0.0f;        // glm::max(x, 0)  -> NaN becomes 0
-    v = (v < 255.0f) ? v : 255.0f;    // glm::min(., 255)
+    // glm::clamp = min(max(x, 0), 255) with glm's `(x < y) ? y : x` forms: NaN becomes 0.  fmaxf / fminf return the
+    // non-NaN operand, so they give the same value (up to the sign of a zero, which the conversion drops) in one
+    // instruction each instead of a compare and a select.
+    v = fmaxf(v, 0.0f);
+    v = fminf(v, 255.0f);
     return (uint32_t)(int)v;
 }
 MIRT_HD uint32_t pack_xrgb(v3 c) { return (chan8(c.x) << 16) | (chan8(c.y) << 8) | chan8(c.z); }
