@@ -32,7 +32,7 @@ struct RtTileFrame {
 };
 __global__ void k_tile_tables(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
-template <int TW> __global__ void k_rt_tile2(const RtTileFrame);
+template <int TW, bool AA> __global__ void k_rt_tile2(const RtTileFrame);
 __global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
 __global__ void k_bin_offsets(const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *);
 struct RtBinnedFrame {
@@ -424,10 +424,10 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         memset(&tf, 0, sizeof tf);
         tf.f = f;
         tf.cam = make_camera_frame(view, y0, y1, g.aa);
-        // two pixels per lane (packed FP32, rt_tile.hip) unless supersampling is on; MIRT_TILE_PX=1 keeps one
+        // two pixels per lane (packed FP32, rt_tile.hip), with or without supersampling; MIRT_TILE_PX=1 keeps one
         static const int tile_px = [] { const char *e = getenv("MIRT_TILE_PX"); return (e && atoi(e) == 1) ? 1 : 2; }();
-        const bool two = f.aa <= 1 && tile_px == 2 && (tile_w == 16 || tile_w == 64);
-        const int tw = two ? (tile_w == 64 ? 32 : 16) : tile_w;
+        const bool two = tile_px == 2 && (tile_w == 16 || tile_w == 64);
+        const int tw = two ? ((tile_w == 64 && f.aa <= 1) ? 32 : 16) : tile_w;
         const int th = (two ? 128 : 64) / tw;
         tf.tiles_x = (view->width + tw - 1) / tw;
         tf.tiles_y = (rows + th - 1) / th;
@@ -456,9 +456,10 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             k_end(MIRT_K_PREP);
         }
         k_begin(MIRT_K_TRACE);
-        if (f.aa > 1) hipLaunchKernelGGL((k_rt_tile<16, true>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
-        else if (two && tw == 16) hipLaunchKernelGGL((k_rt_tile2<16>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
-        else if (two) hipLaunchKernelGGL((k_rt_tile2<32>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
+        if (two && f.aa > 1) hipLaunchKernelGGL((k_rt_tile2<16, true>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
+        else if (f.aa > 1) hipLaunchKernelGGL((k_rt_tile<16, true>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        else if (two && tw == 16) hipLaunchKernelGGL((k_rt_tile2<16, false>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
+        else if (two) hipLaunchKernelGGL((k_rt_tile2<32, false>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
         else if (tile_w == 8) hipLaunchKernelGGL((k_rt_tile<8, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
         else if (tile_w == 16) hipLaunchKernelGGL((k_rt_tile<16, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
         else hipLaunchKernelGGL((k_rt_tile<64, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);

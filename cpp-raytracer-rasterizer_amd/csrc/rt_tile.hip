@@ -302,9 +302,9 @@ __global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
 // The same tile algorithm with a wave owning TW x (128/TW) pixels: lane l carries pixel (lx, ly) and the pixel
 // 64/TW rows below it.  Every multiply and add of the two rays shares one packed instruction (mirt_math2.hpp), the
 // LDS rows of a candidate triangle are read once for both rays, and the per-tile work (candidate masks, direction-box
-// reductions) is spread over twice the pixels.  No supersampling here (k_rt_tile<16, true> keeps that).
+// reductions) is spread over twice the pixels.  With supersampling each half carries its own sub-ray position.
 
-template <int TW>
+template <int TW, bool AA>
 __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty, const TileTables &tb)
 {
     constexpr int TH = 64 / TW;                   // rows per half; the tile is 2*TH rows tall
@@ -314,6 +314,9 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
     const int x = x0 + (lane % TW), ya = y0 + (lane / TW), yb = ya + TH;
     const bool okx = x < f.W, ok0 = okx && ya < f.y1, ok1 = okx && yb < f.y1;
     const v3 cam = ld3(f.cam);
+
+    const int rs = AA ? f.aa : 1;                 // realSamples (:549-554); compile-time 1 without supersampling: the loops fold away
+    const float reach = rs > 1 ? 0.5f : 0.0f;
 
     // ---- primary candidates: one lane per triangle tests the tile's pixel rectangle ----
     bool cand = false;
@@ -326,7 +329,9 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
         t.s.c0 = d4.x; t.s.cu = d4.y; t.s.cv = d4.z; t.s.m = d4.w;
         t.nb = tb.cam[3 * lane].w;
         t.bstate = BOX_NONE; t.bu0 = t.bu1 = t.bv0 = t.bv1 = 0.0f;
-        cand = rect_may_hit(t, (float)x0, (float)min(x0 + TW - 1, f.W - 1), (float)y0, (float)min(y0 + 2 * TH - 1, f.y1 - 1));
+        // (with supersampling the sub-rays reach half a pixel beyond the pixel centres on every side)
+        cand = rect_may_hit(t, (float)x0 - reach, (float)min(x0 + TW - 1, f.W - 1) + reach,
+                            (float)y0 - reach, (float)min(y0 + 2 * TH - 1, f.y1 - 1) + reach);
     }
     const unsigned long long pmask = __ballot(cand);
     unsigned ntests = 0;                                                     // ray-triangle tests this lane runs
@@ -336,7 +341,13 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
     v3 pos0 = V3(0.0f, 0.0f, 0.0f), pos1 = pos0;
     // d = (x - W/2, y - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
     const float hw = (float)f.W / 2.0f, hh = (float)f.H / 2.0f;
-    const v3p d = V3P(splat2((float)x - hw), (f2){ (float)ya - hh, (float)yb - hh }, splat2(f.focal));
+    v3p avg = splat3(V3(0.0f, 0.0f, 0.0f));
+    // sub-ray stepping of Draw() (:566-596): both pixels of the lane share x, each half carries its own x1 / y1
+    f2 y1 = { aa_start(ya, rs), aa_start(yb, rs) };
+    for (int z = 0; z < rs; z++) {
+    f2 x1 = splat2(aa_start(x, rs));
+    for (int z2 = 0; z2 < rs; z2++) {
+    const v3p d = V3P(x1 - splat2(hw), y1 - splat2(hh), splat2(f.focal));
     const v3p nd = neg3p(mat3_mul_vecp(f.rot, d));
     bool any0 = false, any1 = false;                                         // ClosestIntersection's return value
     {
@@ -366,9 +377,8 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
     const bool hit0 = ok0 && any0, hit1 = ok1 && any1;
     count_hits(f, (unsigned long long)(__popcll(__ballot(hit0)) + __popcll(__ballot(hit1))));
 
-    v3p avg = splat3(V3(0.0f, 0.0f, 0.0f));
     if (__any(hit0 || hit1)) {
-        const v3p pos = join3(pos0, pos1);
+        const v3p pos = join3(pos0, pos1);                                   // the record carried across sub-rays (:243-247)
         const int s0 = bi0 >= 0 ? bi0 : 0, s1 = bi1 >= 0 ? bi1 : 0;
         const float4 sa0 = tb.shade[2 * s0], sa1 = tb.shade[2 * s0 + 1], sb0 = tb.shade[2 * s1], sb1 = tb.shade[2 * s1 + 1];
         const v3p nDir = join3(V3(sa0.x, sa0.y, sa0.z), V3(sb0.x, sb0.y, sb0.z));   // glm::normalize(normal) (:300), per triangle
@@ -428,9 +438,16 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
         const v3p Dl = mul3p(result2, tcol);                                 // :325-326
         const v3p shaded = add3p(avg, mul3p(tcol, add3p(Dl, splat3(ld3(f.indirect)))));   // :584-591 (avgColor += R)
         avg = join3(hit0 ? half0(shaded) : half0(avg), hit1 ? half1(shaded) : half1(avg));
+        if (AA) x1 = x1 + (f2){ hit0 ? aa_step(rs) : 0.0f, hit1 ? aa_step(rs) : 0.0f };   // :593, only after a hit
     }
+    }   // z2
+    if (AA) y1 = y1 + splat2(aa_step(rs));                                   // :596
+    }   // z
     count_tests(f, ntests);
-    // avgColor /= 1*1 is the identity (:599)
+    if (AA) {                                                                // avgColor /= realSamples^2 (:599); /1 is the identity
+        const f2 q = splat2((float)(rs * rs));
+        avg = V3P(avg.x / q, avg.y / q, avg.z / q);
+    }
     if (ok0) {
         const v3 c = half0(avg);
         const size_t px = (size_t)ya * f.W + x;
@@ -451,7 +468,7 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
     }
 }
 
-template <int TW>
+template <int TW, bool AA>
 __global__ __launch_bounds__(1024) void k_rt_tile2(const RtTileFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
@@ -459,11 +476,12 @@ __global__ __launch_bounds__(1024) void k_rt_tile2(const RtTileFrame tf)
     const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
     const int waves = blockDim.x >> 6;
     for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves)
-        tile_body2<TW>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), tab);
+        tile_body2<TW, AA>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), tab);
 }
 
-template __global__ void k_rt_tile2<16>(const RtTileFrame);
-template __global__ void k_rt_tile2<32>(const RtTileFrame);
+template __global__ void k_rt_tile2<16, false>(const RtTileFrame);
+template __global__ void k_rt_tile2<32, false>(const RtTileFrame);
+template __global__ void k_rt_tile2<16, true>(const RtTileFrame);
 
 template __global__ void k_rt_tile<8, false>(const RtTileFrame);
 template __global__ void k_rt_tile<16, false>(const RtTileFrame);
