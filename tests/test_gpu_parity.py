@@ -728,3 +728,18 @@ def test_raster_on_random_configurations(oracle, seed):
     lights[:, 3:6] = rng.uniform(0.2, 1.0, (nl, 3))
     lights[:, 6] = rng.uniform(3, 20, nl)
     _raster_compare(oracle, tris, cam, rot, float(rng.uniform(0.5, 1.3) * H), W, H, lights, cull_flags=seed % 4)
+
+
+def test_rt_binned_frame_with_more_than_64_level0_cells(oracle):
+    """A 4104 x 4104 frame has 9 x 9 = 81 cells of 64 x 64 bins, more than the 64-bit level-0 mask a lane keeps for a huge
+    item; the walk then tests the cells itself.  Cornell walls (huge items covering most of the screen) + a sparse soup,
+    binned against brute force."""
+    tris = np.concatenate([mirt.scene_cornell(), mirt.scene_soup(77, 400, 0.25)])
+    W = H = 4104
+    mirt.scene_upload(tris)
+    view = mirt.make_view((0.1, -0.05, -2.2), oracle.rot_from_yaw(0.05, 1.0), H / 2.0, W, H)
+    a = mirt.raytrace(view, DEFAULT_LIGHT, mode=mirt.RT_BINNED, want_rgb=False)
+    b = mirt.raytrace(view, DEFAULT_LIGHT, mode=mirt.RT_BRUTE, want_rgb=False)
+    assert a["stats"]["mode_used"] == mirt.RT_BINNED
+    assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["xrgb"], b["xrgb"])
+    assert a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
