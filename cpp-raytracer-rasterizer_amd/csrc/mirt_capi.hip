@@ -122,11 +122,13 @@ struct Ctx {
     int aa = 1;                                  // realSamples of Draw(): AA_SAMPLES when AA_ENABLED, else 1
     int dof_k = 0;                               // DOF_KERNEL_SIZE when DOF_ENABLED, else 0
     float dof_focal = 0.0f;                      // FOCAL_LENGTH
-    float *d_dof_rgb = nullptr, *d_dof_fd = nullptr;     // pixelColours / focalDistances of the band + halo
-    uint32_t *d_dof_xrgb = nullptr;              // unblurred words the render kernels emit (discarded)
-    int32_t *d_dof_index = nullptr;
-    float *d_dof_zinv = nullptr;
-    size_t dof_cap_px = 0;
+    struct DofPlanes {                           // one set per stream (frames in flight)
+        float *rgb = nullptr, *fd = nullptr;     // pixelColours / focalDistances of the band + halo
+        uint32_t *xrgb = nullptr;                // unblurred words the render kernels emit (discarded)
+        int32_t *index = nullptr;
+        float *zinv = nullptr;
+        size_t cap_px = 0;
+    } dof[2];
     int soft_npos = 0;
     float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
 
@@ -382,9 +384,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     const size_t tile_lds = (size_t)g.n * 16 * (12 + 3 * nlights);
     const bool tile_path = !binned && safe && tile_w && g.n <= 64 && tile_lds <= 64 * 1024;
 
-    // A frame reads the scene and writes the caller's planes plus its stream's own tables and counters, so frames may
-    // overlap (call_begin); with depth of field the planes are the library's own and frames must not.
-    call_begin(d_fd == nullptr);
+    // A frame reads the scene and writes the caller's planes plus its stream's own tables, counters and depth-of-field
+    // planes, so frames may overlap (call_begin).
+    call_begin(true);
     g.pending_is_rt = true;
     g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0) * (uint64_t)((g.aa > 1 ? g.aa : 1) * (g.aa > 1 ? g.aa : 1));
     g.pending_nlights = light_positions;
@@ -668,23 +670,25 @@ int render_with_dof(const mirt_view *view, int y0, int y1, int row_origin, void 
     const int reach = std::max(-zlo, zhi - 1) + 1;           // +1: a tap column outside the row wraps into the next row
     const int ry0 = std::max(0, y0 - reach), ry1 = std::min(H, y1 + reach);
     const size_t npx = (size_t)W * (size_t)(ry1 - ry0);
-    if (npx > g.dof_cap_px) {
-        for (void **p : { (void **)&g.d_dof_rgb, (void **)&g.d_dof_fd, (void **)&g.d_dof_xrgb, (void **)&g.d_dof_index, (void **)&g.d_dof_zinv }) {
+    // the stream call_begin() will give this frame (it is self-contained: its planes are this stream's own)
+    Ctx::DofPlanes &D = g.dof[g.in_flight == 2 ? (g.last_stream ^ 1) : 0];
+    if (npx > D.cap_px) {
+        for (void **p : { (void **)&D.rgb, (void **)&D.fd, (void **)&D.xrgb, (void **)&D.index, (void **)&D.zinv }) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
-        g.dof_cap_px = 0;
-        if (hipMalloc((void **)&g.d_dof_rgb, npx * 12) != hipSuccess || hipMalloc((void **)&g.d_dof_fd, npx * 4) != hipSuccess ||
-            hipMalloc((void **)&g.d_dof_xrgb, npx * 4) != hipSuccess || hipMalloc((void **)&g.d_dof_index, npx * 4) != hipSuccess ||
-            hipMalloc((void **)&g.d_dof_zinv, npx * 4) != hipSuccess)
+        D.cap_px = 0;
+        if (hipMalloc((void **)&D.rgb, npx * 12) != hipSuccess || hipMalloc((void **)&D.fd, npx * 4) != hipSuccess ||
+            hipMalloc((void **)&D.xrgb, npx * 4) != hipSuccess || hipMalloc((void **)&D.index, npx * 4) != hipSuccess ||
+            hipMalloc((void **)&D.zinv, npx * 4) != hipSuccess)
             return fail(MIRT_ERR_OUT_OF_MEMORY, "depth-of-field planes (%zu pixels)", npx);
-        g.dof_cap_px = npx;
+        D.cap_px = npx;
     }
     // the kernels index their planes with full-frame pixel numbers: shift the bases so that row ry0 is the first stored
     const ptrdiff_t shift = (ptrdiff_t)ry0 * W;
-    float *rgb = g.d_dof_rgb - 3 * shift, *fd = g.d_dof_fd - shift, *zinv = g.d_dof_zinv - shift;
-    int32_t *index = g.d_dof_index - shift;
-    if ((rc = render(ry0, ry1, (void *)g.d_dof_xrgb, (void *)rgb, (void *)fd, user_index ? (void *)index : nullptr,
+    float *rgb = D.rgb - 3 * shift, *fd = D.fd - shift, *zinv = D.zinv - shift;
+    int32_t *index = D.index - shift;
+    if ((rc = render(ry0, ry1, (void *)D.xrgb, (void *)rgb, (void *)fd, user_index ? (void *)index : nullptr,
                      user_zinv ? (void *)zinv : nullptr))) return rc;
     if (y1 > y0) {
         DofFrame d;
@@ -696,9 +700,9 @@ int render_with_dof(const mirt_view *view, int y0, int y1, int row_origin, void 
         if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * MIRT_K_DOF + 1], g.stream);
         HIP_TRY(hipGetLastError());
         const size_t rows = (size_t)(y1 - y0), off = (size_t)(y0 - ry0) * W, uoff = (size_t)y0 * W;
-        if (user_rgb) HIP_TRY(hipMemcpyAsync((float *)user_rgb + 3 * uoff, g.d_dof_rgb + 3 * off, rows * W * 12, hipMemcpyDeviceToDevice, g.stream));
-        if (user_index) HIP_TRY(hipMemcpyAsync((int32_t *)user_index + uoff, g.d_dof_index + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
-        if (user_zinv) HIP_TRY(hipMemcpyAsync((float *)user_zinv + uoff, g.d_dof_zinv + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
+        if (user_rgb) HIP_TRY(hipMemcpyAsync((float *)user_rgb + 3 * uoff, D.rgb + 3 * off, rows * W * 12, hipMemcpyDeviceToDevice, g.stream));
+        if (user_index) HIP_TRY(hipMemcpyAsync((int32_t *)user_index + uoff, D.index + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
+        if (user_zinv) HIP_TRY(hipMemcpyAsync((float *)user_zinv + uoff, D.zinv + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
         (void)hipEventRecord(g.ev[EV_CALL1], g.stream);          // the call ends after the blur
     }
     return MIRT_OK;
@@ -761,7 +765,8 @@ extern "C" void mirt_shutdown(void)
                          (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp })
             if (p) (void)hipFree(p);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv,
-                     (void *)g.d_dof_rgb, (void *)g.d_dof_fd, (void *)g.d_dof_xrgb, (void *)g.d_dof_index, (void *)g.d_dof_zinv })
+                     (void *)g.dof[0].rgb, (void *)g.dof[0].fd, (void *)g.dof[0].xrgb, (void *)g.dof[0].index, (void *)g.dof[0].zinv,
+                     (void *)g.dof[1].rgb, (void *)g.dof[1].fd, (void *)g.dof[1].xrgb, (void *)g.dof[1].index, (void *)g.dof[1].zinv })
         if (p) (void)hipFree(p);
     raster_scratch_free(g.raster[0]);
     raster_scratch_free(g.raster[1]);
@@ -950,9 +955,9 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     if (y0 < 0 || y1 > view->height || y0 > y1) return fail(MIRT_ERR_INVALID_ARGUMENT, "row band [%d,%d) outside [0,%d)", y0, y1, view->height);
     if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
 
-    // A rasteriser frame touches the scene (read only) and its stream's own scratch, so frames may overlap (call_begin);
-    // with depth of field the planes are the library's own and frames must not.
-    call_begin(d_fd == nullptr);
+    // A rasteriser frame touches the scene (read only) and its stream's own scratch and depth-of-field planes, so frames
+    // may overlap (call_begin).
+    call_begin(true);
     RasterScratch &scratch = g.raster[(g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0];
     g.pending_is_rt = false;
     if (y1 == y0) { call_end(); return MIRT_OK; }

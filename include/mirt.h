@@ -105,8 +105,8 @@ MIRT_API void *mirt_stream(void);
  * alternate between two streams; the next frame is dispatched while the previous one drains, which hides the
  * dispatch gap between frames).  With 2 the caller must give consecutive frames DIFFERENT output planes -- the
  * double buffering a render loop that presents one frame while drawing the next already has (the reference's
- * SDL_UpdateRect after Draw(), raytracer.cpp:653) -- and mirt_sync() before reading them.  Calls whose internal
- * state is shared between frames (binned mode, the rasteriser, depth of field) are still ordered one after the other. */
+ * SDL_UpdateRect after Draw(), raytracer.cpp:653) -- and mirt_sync() before reading them.  Every scratch buffer a frame
+ * writes (origin and bin tables, raster keys, depth-of-field planes, counters) exists once per stream. */
 MIRT_API int mirt_set_frames_in_flight(int frames);
 
 /* ---- scene --------------------------------------------------------------------------------------- */
