@@ -743,3 +743,37 @@ def test_rt_binned_frame_with_more_than_64_level0_cells(oracle):
     assert a["stats"]["mode_used"] == mirt.RT_BINNED
     assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["xrgb"], b["xrgb"])
     assert a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"]
+
+
+def test_two_frames_in_flight_with_depth_of_field(oracle):
+    """Depth-of-field frames (library-owned pixelColours / focalDistances planes, one set per stream) of two views, ray
+    traced and rasterised alternately into four surfaces with two frames in flight, against the same frames one at a time."""
+    tris = mirt.scene_cornell()
+    W, H = 210, 150
+    va = mirt.make_view((0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), 75.0, W, H)
+    vb = mirt.make_view((0.15, 0.1, -2.6), oracle.rot_from_yaw(-0.3, 1.01), 110.0, W, H)
+    mirt.scene_upload(tris, mirt.cull(tris, vb, 3))
+    mirt.set_depth_of_field(8, 1.6)
+    surf = [_DeviceWords(W, H, 0x11 * (i + 1)) for i in range(4)]
+    try:
+        want = []
+        for i, (v, rt) in enumerate([(va, True), (vb, False), (vb, True), (va, False)]):
+            if rt:
+                mirt.raytrace_device(v, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, surf[i].ptr, W * 4)
+            else:
+                mirt.rasterise_device(v, DEFAULT_LIGHT, (0.2, 0.2, 0.2), 0, H, 0, surf[i].ptr, W * 4)
+            want.append(surf[i].read())
+        assert not np.array_equal(want[0], want[2])
+        mirt.set_frames_in_flight(2)
+        for _ in range(25):
+            mirt.raytrace_device(va, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, surf[0].ptr, W * 4)
+            mirt.rasterise_device(vb, DEFAULT_LIGHT, (0.2, 0.2, 0.2), 0, H, 0, surf[1].ptr, W * 4)
+            mirt.raytrace_device(vb, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, surf[2].ptr, W * 4)
+            mirt.rasterise_device(va, DEFAULT_LIGHT, (0.2, 0.2, 0.2), 0, H, 0, surf[3].ptr, W * 4)
+        for i in range(4):
+            assert np.array_equal(surf[i].read(), want[i]), "surface %d" % i
+    finally:
+        mirt.set_frames_in_flight(1)
+        mirt.set_depth_of_field(0)
+        for s in surf:
+            s.free()
