@@ -58,7 +58,7 @@ __device__ __forceinline__ bool cell_may_hit(const BinItem &u, const float (&A)[
 
 struct BinFrameGrid { int nbu, fj0, fj1, cells_x, cy0, ncell; uint32_t fbase; };
 
-constexpr int BIN_PAIR_BUF = 4096;                    // pairs a workgroup stages in LDS between flushes (32 KiB)
+constexpr int BIN_PAIR_BUF = 2048;                    // pairs a workgroup stages in LDS between flushes (16 KiB)
 constexpr int BIN_DIRECT_SIDE = 32;                   // boxes up to 32 x 32 bins are tested bin by bin, flattened over the workgroup
 
 // Where the pairs of the huge items go: the workgroup's LDS buffer, allocated with an LDS atomic per level-2 step, and
