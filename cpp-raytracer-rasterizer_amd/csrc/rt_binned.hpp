@@ -27,7 +27,7 @@
 namespace mirt {
 
 constexpr int BIN_TILE = 8;            // camera bins are 8x8 pixels = one wave64
-constexpr int BIN_COARSE = 8;          // coarse cell = 8x8 fine bins (hierarchical test)
+constexpr int BIN_COARSE = 8;          // coarse cell = 8x8 fine bins (the three-level walk of huge items, rt_binned.hip)
 constexpr int CUBE_BINS_MIN = 64;      // per-face light-cube grid is B x B; B = 64 by default (128 / 256 selectable)
 constexpr int MAX_BIN_FRAMES = 1 + 6 * MIRT_MAX_LIGHTS;
 
@@ -48,8 +48,8 @@ struct BinSet {
     const BinFrameDesc *frames;   // device array
     int nframes;
     uint32_t nbins;               // total bins over all frames
-    uint32_t *bin_off;            // nbins + 1: exclusive scan of the counts (bin_off[nbins] = total entries)
-    uint32_t *entries;            // candidate triangle indices
+    uint32_t *bin_off;            // nbins + 1: first entry of every bin (bin_off[nbins] = total entries), k_bin_offsets
+    uint32_t *entries;            // candidate triangle indices ordered by bin (the sorted pair values)
     uint32_t cap_entries;
     uint32_t *counters;           // [0] pairs produced by k_bin_pairs (may exceed the capacity: then the frame is redone)
 };

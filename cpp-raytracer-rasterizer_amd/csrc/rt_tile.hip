@@ -2,16 +2,17 @@
 // everything lives in LDS and every wave prunes the triangle list for its tile before it walks it.
 //
 // k_rt_small (rt_kernels.hip) already keeps the whole scene in LDS, but each of its rays still runs the filter
-// against all n triangles, twice (primary + shadow).  Here a wave owns a TW x (64/TW) pixel tile and first builds
-// two 64-bit candidate masks with ONE lane per triangle:
+// against all n triangles, twice (primary + shadow).  Here a wave owns a pixel tile -- 16 x 8 with two pixels per lane
+// (tile_body2, packed FP32, the default) or TW x (64/TW) with one (tile_body) -- and first builds two 64-bit candidate
+// masks with ONE lane per triangle:
 //   * primary rays: the conservative rectangle test of rt_binned.hpp (affine edge functions of the camera frame
 //     over the tile's pixel rectangle);
 //   * shadow rays of light k: the same sign conditions evaluated with interval arithmetic over the bounding box of
-//     the wave's shadow-ray directions (three xor-butterfly min/max reductions).
+//     the wave's shadow-ray directions (six 64-lane min/max reductions in DPP, no LDS traffic).
 // The wave then walks only the set bits, in ascending index order, with the very same filter + exact arithmetic as
 // every other kernel -- so the `>=` tie rule and all results stay bit-identical (a pruned triangle could never have
-// been accepted by any ray of the wave).  Per-triangle normalised normals and colours sit in LDS too, and each
-// workgroup renders several tiles per wave so the table build is amortised.
+// been accepted by any ray of the wave).  The per-frame tables (origin rows, geometry, edge functions, normalised
+// normals, colours) are built once per frame by k_tile_tables and copied into LDS by every workgroup; one tile per wave.
 #include "rt_binned.hpp"
 
 #include <float.h>
