@@ -56,6 +56,52 @@ __device__ __forceinline__ bool cell_may_hit(const BinItem &u, const float (&A)[
     return ok && (I + K >= u.lou) && (I <= u.hiu) && (J + K >= u.lov) && (J <= u.hiv);
 }
 
+// ---- joint emptiness of a huge item's accept region inside the frame ---------------------------------------------
+// Every accepted ray has all four folded functions G_k(u,v) = sgn*g_k(u,v) + m_k >= 0 at its (u,v) (that is what the cell
+// tests rely on), and lies inside the frame's rectangle: eight half-planes.  The cell tests look at one function at a time
+// (is it >= 0 SOMEWHERE in the cell?), which cannot see that the half-planes have no COMMON point -- a triangle behind a
+// cube face's plane, or crossing it far outside the face, passes them in a dozen bins around the crossings of its edge
+// lines.  By Helly's theorem the eight convex sets have a common point iff every three of them have, and three half-planes
+// a_i + b_i.x >= 0 have none exactly when some weights w_i >= 0 (not all zero) give sum(w_i b_i) = 0 and sum(w_i a_i) < 0
+// (Farkas); in the plane those weights are the pairwise cross products of the gradients.  Triples with two or three
+// rectangle sides are the corner tests level 0 already does, so 4 + 6*4 triples remain.  Rounding: the computed weights
+// are off by at most 2^-22 of their two products, which leaves a residual gradient; the certificate is accepted only below
+// minus 2^-20 * sum(W_i * (|a_i| + |b_i|.(U,V))) with W_i the sum of the two product magnitudes.
+struct BinLin { float a, bu, bv; };
+
+__device__ __forceinline__ bool bin_triple_infeasible(const BinLin &f, const BinLin &g, const BinLin &h, float U, float V)
+{
+    const float f1 = g.bu * h.bv, f2 = g.bv * h.bu, g1 = h.bu * f.bv, g2 = h.bv * f.bu, h1 = f.bu * g.bv, h2 = f.bv * g.bu;
+    float wf = f1 - f2, wg = g1 - g2, wh = h1 - h2;
+    const bool pos = wf >= 0.0f && wg >= 0.0f && wh >= 0.0f, neg = wf <= 0.0f && wg <= 0.0f && wh <= 0.0f;
+    if (!(pos || neg)) return false;                 // the gradients do not positively span the plane (also NaN)
+    if (neg) { wf = -wf; wg = -wg; wh = -wh; }
+    if (!(wf + wg + wh > 0.0f)) return false;
+    const float C = wf * f.a + wg * g.a + wh * h.a;
+    const float slack = (fabsf(f1) + fabsf(f2)) * (fabsf(f.a) + fabsf(f.bu) * U + fabsf(f.bv) * V) +
+                        (fabsf(g1) + fabsf(g2)) * (fabsf(g.a) + fabsf(g.bu) * U + fabsf(g.bv) * V) +
+                        (fabsf(h1) + fabsf(h2)) * (fabsf(h.a) + fabsf(h.bu) * U + fabsf(h.bv) * V);
+    return C < -9.5367431640625e-07f * slack;        // 2^-20
+}
+
+// true: no (u,v) of the frame's rectangle [u0,u1] x [v0,v1] satisfies all four G_k >= 0
+__device__ __forceinline__ bool bin_jointly_empty(const BinLin (&G)[4], float u0, float u1, float v0, float v1)
+{
+    const float U = fmaxf(fabsf(u0), fabsf(u1)), V = fmaxf(fabsf(v0), fabsf(v1));
+    const BinLin side[4] = { { -u0, 1.0f, 0.0f }, { u1, -1.0f, 0.0f }, { -v0, 0.0f, 1.0f }, { v1, 0.0f, -1.0f } };
+    bool empty = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) {
+#pragma unroll
+            for (int k = j + 1; k < 4; k++) empty = empty || bin_triple_infeasible(G[i], G[j], G[k], U, V);
+#pragma unroll
+            for (int sd = 0; sd < 4; sd++) empty = empty || bin_triple_infeasible(G[i], G[j], side[sd], U, V);
+        }
+    return empty;
+}
+
 struct BinFrameGrid { int nbu, fj0, fj1, cells_x, cy0, ncell; uint32_t fbase; };
 
 constexpr int BIN_PAIR_BUF = 2048;                    // pairs a workgroup stages in LDS between flushes (16 KiB)
@@ -245,6 +291,15 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
                 }
                 if (gr.ncell > 64) cells = ~0ull;          // more cells than mask bits (frames beyond 4096 x 4096 bins): the walk tests them
                 if (!cells) kind = 0;
+                // ... and the joint test: is there ANY point of the frame where all four functions hold at once?
+                if (kind == 2 && !both) {
+                    BinLin G[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { G[k].a = sgn * fn[k]->c0 + fn[k]->m; G[k].bu = sgn * fn[k]->cu; G[k].bv = sgn * fn[k]->cv; }
+                    const float u0 = fr.ulo + fr.pad_lo, u1 = fr.ulo + (float)nbu * fr.du + fr.pad_hi;
+                    const float v0 = fr.vlo + (float)fj0 * fr.dv + fr.pad_lo, v1 = fr.vlo + (float)fj1 * fr.dv + fr.pad_hi;
+                    if (bin_jointly_empty(G, u0, u1, v0, v1)) kind = 0;
+                }
             }
         }
 
