@@ -243,6 +243,8 @@ void call_begin(bool self_contained = false)
         g.last_self_contained = self_contained;
     }
     g.frame_no++;
+    (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (torch polls events:
+                                                 // hipErrorNotReady) so that the launch checks below report our own launches only
     memset(&g.stats, 0, sizeof g.stats);
     memset(g.ev_used, 0, sizeof g.ev_used);
     (void)hipEventRecord(g.ev[EV_CALL0], g.stream);

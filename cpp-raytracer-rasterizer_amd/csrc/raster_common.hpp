@@ -45,6 +45,7 @@ struct RasterScratch {
     int cap_tris = 0;
     size_t cap_rows = 0;
     size_t cap_px = 0;
+    size_t keys_zero_px = 0;         // keys[0 .. keys_zero_px) are known to be zero (k_raster_resolve re-zeroes what a frame used)
     // sizing cache: the total row count of the previous frame with the same inputs
     uint64_t sizing_key = 0;
     bool sizing_valid = false;

@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = f.y0 + blockIdx.y;
     if (x >= f.W) return;
-    const unsigned long long key = f.scratch.keys[(size_t)(y - f.y0) * f.W + x];
+    unsigned long long *kp = f.scratch.keys + (size_t)(y - f.y0) * f.W + x;
+    const unsigned long long key = *kp;
+    if (key != 0ull) *kp = 0ull;                 // leave the depth keys cleared for the next frame (Update() :188): no memset per frame
     v3 colour = V3(0.0f, 0.0f, 0.0f);            // Update() cleared pixelColours (:189)
     float zinv = 0.0f;                           // and depthBuffer (:188)
     float fdist = 0.0f;
@@ -397,6 +399,7 @@ int raster_scratch_ensure(RasterScratch &s, int n, int W, int band_rows)
     }
     const size_t px = (size_t)W * band_rows;
     if (px > s.cap_px) {
+        s.keys_zero_px = 0;
         if (grow((void **)&s.keys, px * sizeof(unsigned long long))) { s.cap_px = 0; return MIRT_ERR_OUT_OF_MEMORY; }
         s.cap_px = px;
     }
@@ -420,9 +423,16 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     auto end = [&](int k) { if (ev) (void)hipEventRecord(ev[2 * k + 1], stream); };
     const int band_rows = f.y1 - f.y0;
 
-    begin(MIRT_K_CLEAR);
-    if (hipMemsetAsync(s.keys, 0, (size_t)f.W * band_rows * sizeof(unsigned long long), stream) != hipSuccess) return MIRT_ERR_HIP;
-    end(MIRT_K_CLEAR);
+    // The depth keys of the band must be zero (depthBuffer cleared by Update(), :188).  k_raster_resolve zeroes every key it
+    // consumes, so after a completed frame the first `keys_zero_px` slots are zero again and only a larger band needs a memset.
+    const size_t band_px = (size_t)f.W * band_rows;
+    if (band_px > s.keys_zero_px) {
+        begin(MIRT_K_CLEAR);
+        s.keys_zero_px = 0;
+        if (hipMemsetAsync(s.keys, 0, band_px * sizeof(unsigned long long), stream) != hipSuccess) return MIRT_ERR_HIP;
+        s.keys_zero_px = band_px;
+        end(MIRT_K_CLEAR);
+    }
 
     begin(MIRT_K_RASTER_SETUP);
     f.scratch = s;
@@ -457,7 +467,8 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     begin(MIRT_K_RASTER_RESOLVE);
     hipLaunchKernelGGL(k_raster_resolve, dim3((f.W + 255) / 256, band_rows), dim3(256), 0, stream, f);
     end(MIRT_K_RASTER_RESOLVE);
-    return hipGetLastError() == hipSuccess ? MIRT_OK : MIRT_ERR_HIP;
+    if (hipGetLastError() != hipSuccess) { s.keys_zero_px = 0; return MIRT_ERR_HIP; }    // the keys may hold fragments nobody consumed
+    return MIRT_OK;
 }
 
 // ---- the cull step of Update() on the device (rasteriser.cpp:404-447): one thread per triangle ----
