@@ -140,6 +140,8 @@ struct Ctx {
     // statistics of the last call
     mirt_stats stats = {};
     bool stats_pending = false;
+    bool call_timed = false;                     // the last call recorded its start / end events (profiling was on)
+    hipStream_t stats_stream = nullptr;          // the stream the last call ran on
     uint64_t pending_primary = 0;
     int pending_nlights = 0;
     bool pending_is_rt = false;
@@ -247,9 +249,12 @@ void call_begin(bool self_contained = false)
                                                  // hipErrorNotReady) so that the launch checks below report our own launches only
     memset(&g.stats, 0, sizeof g.stats);
     memset(g.ev_used, 0, sizeof g.ev_used);
-    (void)hipEventRecord(g.ev[EV_CALL0], g.stream);
+    // the call's own start / end events only when profiling is on: an event record costs ~2.7 us of host time, a quarter of
+    // a 500 x 500 Cornell frame (12.9 -> 7.x us per frame without the two of them)
+    g.call_timed = g.profiling;
+    if (g.call_timed) (void)hipEventRecord(g.ev[EV_CALL0], g.stream);
 }
-void call_end() { (void)hipEventRecord(g.ev[EV_CALL1], g.stream); g.stats_pending = true; }
+void call_end() { if (g.call_timed) (void)hipEventRecord(g.ev[EV_CALL1], g.stream); g.stats_stream = g.stream; g.stats_pending = true; }
 
 // ---- ray tracer --------------------------------------------------------------------------------------
 
@@ -707,7 +712,7 @@ int render_with_dof(const mirt_view *view, int y0, int y1, int row_origin, void 
         if (user_rgb) HIP_TRY(hipMemcpyAsync((float *)user_rgb + 3 * uoff, D.rgb + 3 * off, rows * W * 12, hipMemcpyDeviceToDevice, g.stream));
         if (user_index) HIP_TRY(hipMemcpyAsync((int32_t *)user_index + uoff, D.index + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
         if (user_zinv) HIP_TRY(hipMemcpyAsync((float *)user_zinv + uoff, D.zinv + off, rows * W * 4, hipMemcpyDeviceToDevice, g.stream));
-        (void)hipEventRecord(g.ev[EV_CALL1], g.stream);          // the call ends after the blur
+        if (g.call_timed) (void)hipEventRecord(g.ev[EV_CALL1], g.stream);   // the call ends after the blur
     }
     return MIRT_OK;
 }
@@ -1040,9 +1045,10 @@ extern "C" int mirt_get_stats(mirt_stats *out)
     if ((rc = need_init())) return rc;
     if (!out) return fail(MIRT_ERR_INVALID_ARGUMENT, "out must not be NULL");
     if (g.stats_pending) {
-        HIP_TRY(hipEventSynchronize(g.ev[EV_CALL1]));
+        HIP_TRY(hipStreamSynchronize(g.stats_stream));               // the stream the last call ran on
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, g.ev[EV_CALL0], g.ev[EV_CALL1]) == hipSuccess) g.stats.gpu_ms = ms;
+        g.stats.gpu_ms = 0.0f;
+        if (g.call_timed && hipEventElapsedTime(&ms, g.ev[EV_CALL0], g.ev[EV_CALL1]) == hipSuccess) g.stats.gpu_ms = ms;
         for (int k = 0; k < 8; k++) {
             g.stats.kernel_ms[k] = 0.0f;
             if (g.profiling && g.ev_used[k] && hipEventElapsedTime(&ms, g.ev[EV_K0 + 2 * k], g.ev[EV_K0 + 2 * k + 1]) == hipSuccess)

@@ -31,6 +31,7 @@ int main(int argc, char **argv)
             app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // raytracer.cpp:116 (draws the soft-shadow jitter from
                                                                      // rand(): do it before anything else can touch the stream)
             check(mirt_init(0), "mirt_init");
+            check(mirt_set_profiling(1), "mirt_set_profiling");       // "Render time" below is the GPU time of the call
             app.LoadTestModel();                                     // :149
             app.cameraRot[1][1] = 1.0f;                              // :162
             for (int loop = 0; loop < 2; loop++) {                   // while (NoQuitMessageSDL())
@@ -45,6 +46,7 @@ int main(int argc, char **argv)
             app.screen = screen;
             app.AddLight(vec3(0, -0.5f, -0.7f), vec3(1, 1, 1), 14);  // rasteriser.cpp:104
             check(mirt_init(0), "mirt_init");
+            check(mirt_set_profiling(1), "mirt_set_profiling");
             if (which == "rasterstl") {                              // #ifdef CUSTOM_MODEL (:106-110)
                 app.LoadSTLFile(argc > 6 ? argv[6] : "Source/enemy1.stl");
                 app.cameraPos = vec3(0, -0.5f, -5.0f);

@@ -75,7 +75,7 @@ typedef struct mirt_stats {
     uint64_t primary_rays;        /* width * rows rendered                                          */
     uint64_t shadow_rays;         /* nlights * (pixels whose primary ray hit)                       */
     uint64_t tests;               /* ray-triangle tests actually executed (0 if not counted)        */
-    float gpu_ms;                 /* hipEvent time of the call's device work on the library stream   */
+    float gpu_ms;                 /* hipEvent time of the call's device work; 0 unless profiling is on   */
     float kernel_ms[8];           /* per-kernel time of the call when profiling is on (see below)    */
     int32_t mode_used;            /* mirt_rt_mode actually used                                      */
 } mirt_stats;
@@ -92,8 +92,8 @@ MIRT_API int mirt_init(int device);
 MIRT_API void mirt_shutdown(void);
 MIRT_API const char *mirt_last_error(void);
 MIRT_API int mirt_abi_version(void);
-/* When on, every kernel launch is bracketed by hipEvents on the library stream and mirt_stats.kernel_ms
- * is filled (costs a few microseconds per launch; off by default). */
+/* When on, every call and every kernel launch is bracketed by hipEvents on the library stream and
+ * mirt_stats.gpu_ms / kernel_ms are filled (costs a few microseconds per event; off by default). */
 MIRT_API int mirt_set_profiling(int on);
 /* Blocks until all work queued by the library has finished. */
 MIRT_API int mirt_sync(void);
