@@ -86,6 +86,9 @@ enum { MIRT_K_PREP = 0, MIRT_K_BIN = 1, MIRT_K_TRACE = 2, MIRT_K_DOF = 3,
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
 
+/* One context per process, driven from one thread at a time (the reference is a single-threaded main loop); the calls
+ * are not re-entrant.  Several processes may share a GPU (one process per GPU under torch.distributed). */
+
 /* Replaces nothing in the reference (it has no device).  Selects HIP device `device` (use the process's
  * LOCAL_RANK under torch.distributed), checks it is gfx950, creates the library stream. */
 MIRT_API int mirt_init(int device);
