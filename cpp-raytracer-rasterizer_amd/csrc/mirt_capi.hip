@@ -375,11 +375,15 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     const uint32_t flags_init[4] = { safe ? 0u : 1u, 0u, 0u, 0u };
 
     // ---- mode: brute force for small scenes, binned otherwise; unsafe operands always render exact brute ----
-    static const int auto_threshold = [] { const char *e = getenv("MIRT_BIN_THRESHOLD"); return e ? atoi(e) : 512; }();
+    // MIRT_RT_AUTO bins when the scene is beyond the tile kernel (65 triangles or more) and the brute-force work, pixels x
+    // triangles, is above ~4e7: binning + sorting costs ~40 us whatever the scene, brute force ~7.5e-10 ms per pixel-triangle
+    // (tools/threshold_sweep.py at 1080p: 65 triangles 0.099 vs 0.043 ms, 300: 0.47 vs 0.079, 800: 1.13 vs 0.097).
+    static const int auto_threshold = [] { const char *e = getenv("MIRT_BIN_THRESHOLD"); return e ? atoi(e) : 65; }();
     // rays per lane of the brute-force / LDS-resident kernels: 2 = packed FP32 filter (188 -> 163 ms on the 100 k soup)
     static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 2; return (p == 1) ? 1 : 2; }();
     bool binned = (mode == MIRT_RT_BINNED) ||
-                  (mode == MIRT_RT_AUTO && g.n >= auto_threshold && (long long)view->width * (y1 - y0) > 4096);
+                  (mode == MIRT_RT_AUTO && g.n >= auto_threshold && (long long)view->width * (y1 - y0) > 4096 &&
+                   (long long)view->width * (y1 - y0) * g.n >= 40000000LL);
     if (!safe) binned = false;
     const int rows = y1 - y0;
 
