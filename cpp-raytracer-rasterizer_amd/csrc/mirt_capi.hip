@@ -102,6 +102,7 @@ struct Ctx {
     int last_stream = 1;                         // index of the stream the previous call ran on (in_flight == 2)
     bool last_self_contained = false;            // ... and whether that call may overlap its neighbours
     hipEvent_t ev_chain = nullptr;               // orders a call after the previous one when it must not overlap it
+    hipEvent_t ev_cull = nullptr;                // orders the frames of the other stream after mirt_cull_device
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_used[8] = {};
 
@@ -133,7 +134,7 @@ struct Ctx {
     float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
 
     // staging for the host-buffer entry points
-    void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr;
+    void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr, *d_pos = nullptr;
     size_t cap_px = 0;
     RasterScratch raster[2];                     // one set of rasteriser scratch per stream (frames in flight)
 
@@ -167,12 +168,12 @@ int dev_realloc(T **p, size_t count)
     return MIRT_OK;
 }
 
-int ensure_staging(size_t px, bool rgb, bool index, bool zinv)
+int ensure_staging(size_t px, bool rgb, bool index, bool zinv, bool pos = false)
 {
     // All staging planes share ONE capacity (g.cap_px pixels): a plane that is first needed by a small frame must
     // still be big enough for every frame size the other planes were already grown to.
     if (px > g.cap_px) {
-        for (void **p : { &g.d_xrgb, &g.d_rgb, &g.d_index, &g.d_zinv }) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        for (void **p : { &g.d_xrgb, &g.d_rgb, &g.d_index, &g.d_zinv, &g.d_pos }) { if (*p) (void)hipFree(*p); *p = nullptr; }
         g.cap_px = px;
     }
     auto grow = [&](void **p, size_t bytes_per_px) -> int {
@@ -187,6 +188,7 @@ int ensure_staging(size_t px, bool rgb, bool index, bool zinv)
     if (rgb && (rc = grow(&g.d_rgb, 12))) return rc;
     if (index && (rc = grow(&g.d_index, 4))) return rc;
     if (zinv && (rc = grow(&g.d_zinv, 4))) return rc;
+    if (pos && (rc = grow(&g.d_pos, 12))) return rc;
     return MIRT_OK;
 }
 
@@ -310,7 +312,8 @@ BinFrameDesc make_camera_frame(const mirt_view *view, int y0, int y1, int aa)
 }
 
 int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect, int mode,
-               int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index, void *d_fd = nullptr)
+               int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index, void *d_fd = nullptr,
+               void *d_dist = nullptr, void *d_pos = nullptr)
 {
     int rc;
     if ((rc = need_init())) return rc;
@@ -363,6 +366,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     f.rgb = static_cast<float *>(d_rgb);
     f.index = static_cast<int32_t *>(d_index);
     f.fd = static_cast<float *>(d_fd);
+    f.dist = static_cast<float *>(d_dist);
+    f.pos = static_cast<float *>(d_pos);
     f.focal_plane = g.dof_focal;
     // The pre-reject filter is proven for finite, moderate operands only (rt_common.hpp); anything else
     // (absurd coordinates, NaN/Inf) renders through the exact-only path.  Ray directions of the primary
@@ -678,6 +683,15 @@ int render_with_dof(const mirt_view *view, int y0, int y1, int row_origin, void 
                     void *user_rgb, void *user_index, void *user_zinv, bool clear_border, Render render)
 {
     int rc;
+    // the caller's surface reaches the blur kernel directly: validate it here, before anything is allocated or launched
+    // (rt_enqueue / raster_enqueue only see the library-owned planes)
+    if ((rc = need_init())) return rc;
+    if (!view) return fail(MIRT_ERR_INVALID_ARGUMENT, "view must not be NULL");
+    if (view->width < 1 || view->height < 1 || view->width > 32768 || view->height > 32768)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "frame size %dx%d out of range [1,32768]", view->width, view->height);
+    if (y0 < 0 || y1 > view->height || y0 > y1) return fail(MIRT_ERR_INVALID_ARGUMENT, "row band [%d,%d) outside [0,%d)", y0, y1, view->height);
+    if (!d_xrgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "xrgb output must not be NULL");
+    if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
     const int W = view->width, H = view->height, K = g.dof_k;
     const int zlo = (int)std::ceil((float)K / -2.0f), zhi = (int)std::ceil((float)K / 2.0f);
     const int reach = std::max(-zlo, zhi - 1) + 1;           // +1: a tap column outside the row wraps into the next row
@@ -755,6 +769,7 @@ extern "C" int mirt_init(int device)
     g.last_stream = 1;
     g.last_self_contained = false;
     HIP_TRY(hipEventCreateWithFlags(&g.ev_chain, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.ev_cull, hipEventDisableTiming));
     for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev[i]));
     for (int i = 0; i < 4; i++) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits2[i]), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
@@ -777,7 +792,7 @@ extern "C" void mirt_shutdown(void)
         for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_bin_off,
                          (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp })
             if (p) (void)hipFree(p);
-    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv,
+    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos,
                      (void *)g.dof[0].rgb, (void *)g.dof[0].fd, (void *)g.dof[0].xrgb, (void *)g.dof[0].index, (void *)g.dof[0].zinv,
                      (void *)g.dof[1].rgb, (void *)g.dof[1].fd, (void *)g.dof[1].xrgb, (void *)g.dof[1].index, (void *)g.dof[1].zinv })
         if (p) (void)hipFree(p);
@@ -785,6 +800,7 @@ extern "C" void mirt_shutdown(void)
     raster_scratch_free(g.raster[1]);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.ev_chain) (void)hipEventDestroy(g.ev_chain);
+    if (g.ev_cull) (void)hipEventDestroy(g.ev_cull);
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
     g = Ctx();
 }
@@ -867,9 +883,19 @@ extern "C" int mirt_cull_device(const mirt_view *view, int flags)
     if (view->width <= 0 || view->height <= 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "frame %d x %d", view->width, view->height);
     CullParams cp;
     cull_setup(view, flags, &cp);
-    HIP_TRY(sync_all());                         // frames in flight read the flags
+    // A barrier call, ordered on the device (no host sync): frames in flight on either stream read the flags, so the
+    // kernel waits for both streams, and every later frame -- whichever stream it takes -- waits for the kernel.
+    const int other = (g.stream == g.streams[0]) ? 1 : 0;
+    if (g.in_flight == 2) {
+        HIP_TRY(hipEventRecord(g.ev_chain, g.streams[other]));
+        HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_chain, 0));
+    }
     hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, g.stream, g.d_tris, g.n, cp, g.d_culled);
     HIP_TRY(hipGetLastError());
+    if (g.in_flight == 2) {
+        HIP_TRY(hipEventRecord(g.ev_cull, g.stream));
+        HIP_TRY(hipStreamWaitEvent(g.streams[other], g.ev_cull, 0));
+    }
     g.scene_version++;
     return MIRT_OK;
 }
@@ -922,20 +948,37 @@ extern "C" int mirt_set_soft_shadows(int samples, const float *positions, int np
 
 // ---- ray tracer -------------------------------------------------------------------------------------
 
+extern "C" int mirt_raytrace_device_ex(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                       int mode, int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes,
+                                       void *d_rgb, void *d_index, void *d_distance, void *d_position)
+{
+    if (g.init && g.dof_k > 1)
+        return render_with_dof(view, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index, nullptr, false,
+                               [&](int ry0, int ry1, void *x, void *rgb, void *fd, void *idx, void *) {
+                                   return rt_enqueue(view, lights, nlights, indirect, mode, ry0, ry1, ry0, x, view->width * 4, rgb, idx, fd,
+                                                     d_distance, d_position);
+                               });
+    return rt_enqueue(view, lights, nlights, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index, nullptr,
+                      d_distance, d_position);
+}
+
 extern "C" int mirt_raytrace_device(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
                                     int mode, int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes,
                                     void *d_rgb, void *d_index)
 {
-    if (g.init && g.dof_k > 1 && view && y0 >= 0 && y1 <= view->height && y0 <= y1 && view->width > 0)
-        return render_with_dof(view, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index, nullptr, false,
-                               [&](int ry0, int ry1, void *x, void *rgb, void *fd, void *idx, void *) {
-                                   return rt_enqueue(view, lights, nlights, indirect, mode, ry0, ry1, ry0, x, view->width * 4, rgb, idx, fd);
-                               });
-    return rt_enqueue(view, lights, nlights, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index);
+    return mirt_raytrace_device_ex(view, lights, nlights, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index,
+                                   nullptr, nullptr);
 }
 
 extern "C" int mirt_raytrace(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
                              int mode, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb, int32_t *out_index)
+{
+    return mirt_raytrace_ex(view, lights, nlights, indirect, mode, out_xrgb, pitch_bytes, out_rgb, out_index, nullptr, nullptr);
+}
+
+extern "C" int mirt_raytrace_ex(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                int mode, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb, int32_t *out_index,
+                                float *out_distance, float *out_position)
 {
     int rc;
     if ((rc = need_init())) return rc;
@@ -944,12 +987,16 @@ extern "C" int mirt_raytrace(const mirt_view *view, const mirt_light *lights, in
     if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
     const int W = view->width, H = view->height;
     const size_t px = (size_t)W * H;
-    if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, false))) return rc;
-    if ((rc = mirt_raytrace_device(view, lights, nlights, indirect, mode, 0, H, 0, g.d_xrgb, W * 4,
-                                   out_rgb ? g.d_rgb : nullptr, out_index ? g.d_index : nullptr))) return rc;
+    // closestIntersections[].distance shares the depth staging plane of the rasteriser entry point; .position gets its own
+    if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, out_distance != nullptr, out_position != nullptr))) return rc;
+    if ((rc = mirt_raytrace_device_ex(view, lights, nlights, indirect, mode, 0, H, 0, g.d_xrgb, W * 4,
+                                      out_rgb ? g.d_rgb : nullptr, out_index ? g.d_index : nullptr,
+                                      out_distance ? g.d_zinv : nullptr, out_position ? g.d_pos : nullptr))) return rc;
     if ((rc = copy_plane_interior(out_xrgb, pitch_bytes, g.d_xrgb, W * 4, W, H))) return rc;
     if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, g.d_rgb, px * 12, hipMemcpyDeviceToHost, g.stream));
     if (out_index) HIP_TRY(hipMemcpyAsync(out_index, g.d_index, px * 4, hipMemcpyDeviceToHost, g.stream));
+    if (out_distance) HIP_TRY(hipMemcpyAsync(out_distance, g.d_zinv, px * 4, hipMemcpyDeviceToHost, g.stream));
+    if (out_position) HIP_TRY(hipMemcpyAsync(out_position, g.d_pos, px * 12, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     return MIRT_OK;
 }
@@ -1011,7 +1058,7 @@ extern "C" int mirt_rasterise_device(const mirt_view *view, const mirt_light *li
                                      int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb,
                                      void *d_zinv, void *d_index)
 {
-    if (g.init && g.dof_k > 1 && view && y0 >= 0 && y1 <= view->height && y0 <= y1 && view->width > 0)
+    if (g.init && g.dof_k > 1)
         return render_with_dof(view, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb, d_index, d_zinv, true,
                                [&](int ry0, int ry1, void *x, void *rgb, void *fd, void *idx, void *zinv) {
                                    return raster_enqueue(view, lights, nlights, indirect, ry0, ry1, ry0, x, view->width * 4, rgb, zinv, idx, fd);

@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
     if (f.rgb) st3(f.rgb + 3 * px, avg);
     if (f.index) f.index[px] = best_i;
     if (f.fd) f.fd[px] = best_i >= 0 ? best_d - f.focal_plane : 0.0f;          // focalDistances (:248-249)
+    store_intersection(f, px, best_i, best_d, pos);
     if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)            // (:618-620)
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }

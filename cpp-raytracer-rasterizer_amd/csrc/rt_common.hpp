@@ -172,6 +172,8 @@ struct RtFrame {
     int32_t *index;             // nullable, stride W
     float *fd;                  // nullable, stride W: focalDistances = closest distance - FOCAL_LENGTH (raytracer.cpp:248-249), 0 on a miss
     float focal_plane;          // FOCAL_LENGTH (:45)
+    float *dist;                // nullable, stride W: closestIntersections[].distance (raytracer.cpp:91-98), FLT_MAX on a miss (:335-339)
+    float *pos;                 // nullable, stride W, 3 floats per pixel: closestIntersections[].position, 0 on a miss
     unsigned long long *hit_count;   // HIT_SHARDS counters, HIT_SHARD_STRIDE u64 apart (see count_hits)
 };
 
@@ -235,6 +237,14 @@ __device__ __forceinline__ void count_tests(const RtFrame &f, unsigned lane_test
         const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x + (threadIdx.x >> 6) * 61u) % HIT_SHARDS;
         atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 1, (unsigned long long)total);
     }
+}
+
+// closestIntersections[pixel] as the frame leaves it (struct Intersection, raytracer.cpp:91-98): distance is the FLT_MAX of
+// Update()'s reset (:335-339) where no triangle was accepted; the reference leaves position uninitialised there, here it is 0.
+__device__ __forceinline__ void store_intersection(const RtFrame &f, size_t px, int best_i, float best_d, v3 pos)
+{
+    if (f.dist) f.dist[px] = best_i >= 0 ? best_d : 3.402823466e+38f;
+    if (f.pos) st3(f.pos + 3 * px, best_i >= 0 ? pos : V3(0.0f, 0.0f, 0.0f));
 }
 
 // Per-light shading term D of DirectLight (raytracer.cpp:294-304) before the shadow test.

@@ -206,6 +206,7 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
         if (f.rgb) st3(f.rgb + 3 * px, out);
         if (f.index) f.index[px] = best_i[p];
         if (f.fd) f.fd[px] = best_i[p] >= 0 ? best_d[p] - f.focal_plane : 0.0f;   // focalDistances (:248-249)
+        store_intersection(f, px, best_i[p], best_d[p], pos[p]);
         // CalculateDOF draws interior pixels only (:618-620); the border keeps its old value
         if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)
             f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(out);
@@ -368,6 +369,7 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
         if (f.rgb) st3(f.rgb + 3 * px, out);
         if (f.index) f.index[px] = best_i[p];
         if (f.fd) f.fd[px] = best_i[p] >= 0 ? best_d[p] - f.focal_plane : 0.0f;   // focalDistances (:248-249)
+        store_intersection(f, px, best_i[p], best_d[p], pos[p]);
         if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)                  // :618-620
             f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(out);
     }
@@ -502,6 +504,7 @@ __device__ __forceinline__ void wave_body(const RtFrame &f)
     if (f.rgb) st3(f.rgb + 3 * px, avg);
     if (f.index) f.index[px] = best_i;
     if (f.fd) f.fd[px] = hit ? min_t_dist(best) - f.focal_plane : 0.0f;   // focalDistances (:248-249)
+    store_intersection(f, px, best_i, min_t_dist(best), pos);
     if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)               // :618-620
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }

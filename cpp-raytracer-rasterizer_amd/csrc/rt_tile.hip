@@ -213,6 +213,7 @@ __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty,
     if (f.rgb) st3(f.rgb + 3 * px, avg);
     if (f.index) f.index[px] = best_i;
     if (f.fd) f.fd[px] = best_i >= 0 ? best_d - f.focal_plane : 0.0f;          // focalDistances (:248-249)
+    store_intersection(f, px, best_i, best_d, pos);
     if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)                      // :618-620
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
@@ -455,6 +456,7 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
         if (f.rgb) st3(f.rgb + 3 * px, c);
         if (f.index) f.index[px] = bi0;
         if (f.fd) f.fd[px] = bi0 >= 0 ? bd0 - f.focal_plane : 0.0f;            // focalDistances (:248-249)
+        store_intersection(f, px, bi0, bd0, pos0);
         if (x >= 1 && x < f.W - 1 && ya >= 1 && ya < f.H - 1)                // :618-620
             f.xrgb[(size_t)(ya - f.row_origin) * f.pitch_words + x] = pack_xrgb(c);
     }
@@ -464,6 +466,7 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
         if (f.rgb) st3(f.rgb + 3 * px, c);
         if (f.index) f.index[px] = bi1;
         if (f.fd) f.fd[px] = bi1 >= 0 ? bd1 - f.focal_plane : 0.0f;
+        store_intersection(f, px, bi1, bd1, pos1);
         if (x >= 1 && x < f.W - 1 && yb >= 1 && yb < f.H - 1)
             f.xrgb[(size_t)(yb - f.row_origin) * f.pitch_words + x] = pack_xrgb(c);
     }

@@ -20,7 +20,7 @@ KERNEL_NAMES = ("prep", "bin", "trace", "dof", "raster_setup", "raster_frag", "r
 EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
-    "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_rasterise",
+    "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats",
 )
 
@@ -73,6 +73,9 @@ def load():
     lib.mirt_raytrace.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]
     lib.mirt_raytrace_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _vp, C.c_int, _vp, _vp]
+    lib.mirt_raytrace_ex.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]
+    lib.mirt_raytrace_device_ex.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            _vp, C.c_int, _vp, _vp, _vp, _vp]
     lib.mirt_rasterise.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]
     lib.mirt_rasterise_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                           _vp, C.c_int, _vp, _vp, _vp]
@@ -233,7 +236,9 @@ def set_soft_shadows(samples, positions=None):
 
 # ---- render (host buffers) --------------------------------------------------------------------------
 
-def raytrace(view, lights7, indirect=(0.2, 0.2, 0.2), mode=RT_AUTO, want_rgb=True, want_index=True, xrgb=None):
+def raytrace(view, lights7, indirect=(0.2, 0.2, 0.2), mode=RT_AUTO, want_rgb=True, want_index=True, xrgb=None,
+             want_intersection=False):
+    """want_intersection adds "dist" and "pos": closestIntersections[].distance / .position (mirt_raytrace_ex)."""
     W, H = view.width, view.height
     larr, nl = make_lights(lights7)
     ind = np.asarray(indirect, np.float32)
@@ -242,8 +247,14 @@ def raytrace(view, lights7, indirect=(0.2, 0.2, 0.2), mode=RT_AUTO, want_rgb=Tru
         "rgb": np.zeros((H, W, 3), np.float32) if want_rgb else None,
         "index": np.zeros((H, W), np.int32) if want_index else None,
     }
-    _check(load().mirt_raytrace(C.byref(view), larr, nl, _ptr(ind), int(mode), _ptr(out["xrgb"]),
-                                out["xrgb"].strides[0], _ptr(out["rgb"]), _ptr(out["index"])))
+    if want_intersection:
+        out["dist"] = np.zeros((H, W), np.float32)
+        out["pos"] = np.zeros((H, W, 3), np.float32)
+        _check(load().mirt_raytrace_ex(C.byref(view), larr, nl, _ptr(ind), int(mode), _ptr(out["xrgb"]),
+                                       out["xrgb"].strides[0], _ptr(out["rgb"]), _ptr(out["index"]), _ptr(out["dist"]), _ptr(out["pos"])))
+    else:
+        _check(load().mirt_raytrace(C.byref(view), larr, nl, _ptr(ind), int(mode), _ptr(out["xrgb"]),
+                                    out["xrgb"].strides[0], _ptr(out["rgb"]), _ptr(out["index"])))
     out["stats"] = stats()
     return out
 
@@ -266,11 +277,16 @@ def rasterise(view, lights7, indirect=(0.2, 0.2, 0.2), want_rgb=True, want_zinv=
 
 # ---- render (device buffers: raw pointers, e.g. torch.Tensor.data_ptr()) -----------------------------
 
-def raytrace_device(view, lights7, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb=None, d_index=None):
+def raytrace_device(view, lights7, indirect, mode, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb=None, d_index=None,
+                    d_dist=None, d_pos=None):
     larr, nl = make_lights(lights7)
     ind = np.asarray(indirect, np.float32)
-    _check(load().mirt_raytrace_device(C.byref(view), larr, nl, _ptr(ind), int(mode), int(y0), int(y1),
-                                       int(row_origin), d_xrgb, int(pitch_bytes), d_rgb, d_index))
+    if d_dist is None and d_pos is None:
+        _check(load().mirt_raytrace_device(C.byref(view), larr, nl, _ptr(ind), int(mode), int(y0), int(y1),
+                                           int(row_origin), d_xrgb, int(pitch_bytes), d_rgb, d_index))
+    else:
+        _check(load().mirt_raytrace_device_ex(C.byref(view), larr, nl, _ptr(ind), int(mode), int(y0), int(y1),
+                                              int(row_origin), d_xrgb, int(pitch_bytes), d_rgb, d_index, d_dist, d_pos))
 
 
 def rasterise_device(view, lights7, indirect, y0, y1, row_origin, d_xrgb, pitch_bytes, d_rgb=None, d_zinv=None,

@@ -182,6 +182,19 @@ MIRT_API int mirt_raytrace_device(const mirt_view *view, const mirt_light *light
                                   const float *indirect, int mode, int y0, int y1, int row_origin,
                                   void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index);
 
+/* The same two calls with the rest of `struct Intersection` (raytracer.cpp:91-98): out_distance / d_distance (nullable, W*H
+ * floats, row stride W) receives closestIntersections[].distance -- the FLT_MAX of Update()'s reset (:335-339) where the
+ * primary ray missed -- and out_position / d_position (nullable, W*H*3 floats) closestIntersections[].position (0 where it
+ * missed; the reference leaves it uninitialised).  With depth of field on, the rows the blur reads beyond the band are
+ * rendered too and their entries of these two planes are written as well. */
+MIRT_API int mirt_raytrace_ex(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                              int mode, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb, int32_t *out_index,
+                              float *out_distance, float *out_position);
+MIRT_API int mirt_raytrace_device_ex(const mirt_view *view, const mirt_light *lights, int nlights,
+                                     const float *indirect, int mode, int y0, int y1, int row_origin,
+                                     void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index,
+                                     void *d_distance, void *d_position);
+
 /* ---- rasteriser: replaces Update()'s clear + Draw() + CalculateDOF() of rasteriser.cpp:183-192,461-529 */
 
 /* One frame into host buffers.  Every word of out_xrgb is written: the whole surface is cleared to black

@@ -386,7 +386,9 @@ ORACLE_API uint64_t mirt_oracle_raytrace_ex(const float *tris15, int n, const fl
 #else
     (void)threads;
 #endif
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : nshadow)
+    /* pixels are independent (:557-602): rows and columns are shared out together, so that a band of a single row (the
+     * full-size checks of BASELINE configs 3 and 5) still uses every thread */
+#pragma omp parallel for collapse(2) schedule(dynamic, 16) reduction(+ : nshadow)
     for (int y = y0; y < y1; y++) {
         for (int x = 0; x < W; x++) {
             size_t px = (size_t)y * W + x;

@@ -27,11 +27,14 @@ def _rt_compare(oracle, tris, cam, rot, focal, W, H, lights, mode=mirt.RT_BRUTE,
     mirt.set_soft_shadows(samples, jitter)
     mirt.set_antialiasing(aa)
     try:
-        got = mirt.raytrace(mirt.make_view(cam, rot, focal, W, H), lights, mode=mode)
+        got = mirt.raytrace(mirt.make_view(cam, rot, focal, W, H), lights, mode=mode, want_intersection=True)
     finally:
         mirt.set_soft_shadows(1)
         mirt.set_antialiasing(1)
     assert np.array_equal(got["index"], ref["index"]), "closest-hit index differs in %d pixels" % int((got["index"] != ref["index"]).sum())
+    # the rest of struct Intersection (raytracer.cpp:91-98): closest distance (FLT_MAX on a miss) and hit position, bit for bit
+    assert np.array_equal(got["dist"].view(np.uint32), ref["dist"].view(np.uint32)), "closest-hit distance not bit-identical"
+    assert np.array_equal(got["pos"].view(np.uint32), ref["pos"].view(np.uint32)), "closest-hit position not bit-identical"
     assert np.max(np.abs(got["rgb"] - ref["rgb"])) <= TOL
     assert np.array_equal(got["rgb"].view(np.uint32), ref["rgb"].view(np.uint32)), "float colours not bit-identical"
     assert np.array_equal(got["xrgb"], ref["xrgb"])
@@ -568,6 +571,36 @@ def test_depth_of_field_limits():
     with pytest.raises(mirt.MirtError):
         mirt.set_depth_of_field(65, 1.0)
     mirt.set_depth_of_field(1, 1.0)                                       # <= 1 switches it off
+
+
+def test_depth_of_field_validates_the_callers_surface():
+    """With the blur on, the caller's surface goes straight to the blur kernel: a NULL surface, a short or unaligned pitch,
+    a bad band or an absurd frame must come back as errors (as they do without the blur), never reach a kernel."""
+    mirt.scene_upload(mirt.scene_cornell())
+    W, H = 64, 48
+    rot = np.eye(3, dtype=np.float32).ravel()
+    view = mirt.make_view((0, 0, -2), rot, 24.0, W, H)
+    surf = _DeviceWords(W, H, 0x42)
+    mirt.set_depth_of_field(8, 1.3)
+    try:
+        for call in (mirt.raytrace_device, None):
+            def run(v, y0, y1, ptr, pitch):
+                if call is not None:
+                    mirt.raytrace_device(v, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, y0, y1, 0, ptr, pitch)
+                else:
+                    mirt.rasterise_device(v, DEFAULT_LIGHT, (0.2, 0.2, 0.2), y0, y1, 0, ptr, pitch)
+            for args in ((view, 0, H, None, W * 4), (view, 0, H, surf.ptr, W * 4 - 4), (view, 0, H, surf.ptr, W * 4 + 2),
+                         (view, -1, H, surf.ptr, W * 4), (view, 0, H + 1, surf.ptr, W * 4), (view, 5, 4, surf.ptr, W * 4),
+                         (mirt.make_view((0, 0, -2), rot, 24.0, 40000, H), 0, H, surf.ptr, 40000 * 4),
+                         (mirt.make_view((0, 0, -2), rot, 24.0, 0, H), 0, H, surf.ptr, W * 4)):
+                with pytest.raises(mirt.MirtError):
+                    run(*args)
+            run(view, 0, H, surf.ptr, W * 4)                               # and a valid call still renders
+        mirt.sync()
+        assert (surf.read()[1:-1, 1:-1] != 0x42424242).any()
+    finally:
+        mirt.set_depth_of_field(0)
+        surf.free()
 
 
 # ---- two frames in flight ---------------------------------------------------------------------------------------

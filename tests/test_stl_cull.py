@@ -156,3 +156,38 @@ def test_host_adapter_custom_model_build(oracle, tmp_path):
     ref = oracle.rasterise(tris, culled, cam, rot, float(H), W, H, DEFAULT_LIGHT)["xrgb"]
     assert np.array_equal(got, ref)
     assert (ref != 0).sum() > 500
+
+
+@pytest.mark.gpu
+def test_cull_on_the_device_is_ordered_between_frames_in_flight(oracle, device):
+    """mirt_cull_device with two frames in flight: the kernel must wait for the frames of BOTH streams and the next frame
+    -- which takes the other stream -- must wait for the kernel.  Frame A (view a), cull for view b, frame B: both frames
+    must equal the oracle's, on a mesh large enough (120 k triangles) for the cull kernel to still run when frame B's
+    vertex kernel starts."""
+    from devbuf import DeviceArray
+    tris = mirt.scene_soup(9, 120000, 0.03)
+    W, H = 480, 270
+    views = [((0.0, 0.0, -3.0), 0.0), ((0.9, 0.1, -2.4), 0.5)]
+    mirt.scene_upload(tris)
+    want = []
+    for cam, yaw in views:
+        rot = oracle.rot_from_yaw(yaw, 1.01)
+        culled = oracle.cull(tris, cam, rot, float(H), W, H, 3)
+        want.append(oracle.rasterise(tris, culled, cam, rot, float(H), W, H, DEFAULT_LIGHT, want=("xrgb", "index")))
+    assert not np.array_equal(want[0]["index"], want[1]["index"])
+    vs = [mirt.make_view(cam, oracle.rot_from_yaw(yaw, 1.01), float(H), W, H) for cam, yaw in views]
+    surf = [DeviceArray((H, W), np.uint32, 0x11), DeviceArray((H, W), np.uint32, 0x22)]
+    idx = [DeviceArray((H, W), np.int32, 0x33), DeviceArray((H, W), np.int32, 0x44)]
+    mirt.set_frames_in_flight(2)
+    try:
+        for rep in range(6):
+            for k in (0, 1):
+                mirt.cull_device(vs[k], 3)
+                mirt.rasterise_device(vs[k], DEFAULT_LIGHT, (0.2, 0.2, 0.2), 0, H, 0, surf[k].ptr, W * 4, None, None, idx[k].ptr)
+        for k in (0, 1):
+            assert np.array_equal(idx[k].read(), want[k]["index"]), "view %d: owner index differs" % k
+            assert np.array_equal(surf[k].read(), want[k]["xrgb"]), "view %d: surface differs" % k
+    finally:
+        mirt.set_frames_in_flight(1)
+        for b in surf + idx:
+            b.free()
