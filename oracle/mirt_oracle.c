@@ -7,17 +7,27 @@
  * never links, loads or falls back to it.
  *
  * PINNING.  The reference's render translation units (raytracer/Source/raytracer.cpp,
- * rasteriser/Source/rasteriser.cpp) #include <SDL.h>; SDL 1.2 is not installed in this image and a
- * stand-in header is not permitted, so they are UNBUILDABLE here and this restatement cannot be
- * diffed against a live reference build.  It is pinned instead by
- *   (1) the known answers recorded from the unmodified reference in SURVEY.md Appendix C
- *       (FNV-1a-64 hashes of the full 500x500 index / colour / depth / screen buffers, histograms,
- *       sampled pixels) -- tests/golden/survey_appendix_c.json, checked by tests/test_oracle_pin.py;
- *   (2) the parts of the reference that DO compile from its own files (TestModel.h + the vendored
- *       GLM), built in place into oracle/_ref/ by oracle/Makefile and compared bit-for-bit
- *       with cornell()/the vec-mat helpers below by tests/test_oracle_ref_model.py.
- * Everything the Appendix-C vectors do not cover (yaw != 0, non-square frames, more than one light,
- * random soups) is "parity unpinned": same code, no recorded reference output.
+ * rasteriser/Source/rasteriser.cpp) #include <SDL.h>; SDL 1.2 is not installed in this image and no
+ * stand-in header is written, so they cannot be built AS A WHOLE.  Their hot-path functions contain no SDL
+ * call, though, and are compiled from the reference's own text.  The restatement is pinned by
+ *   (1) the reference's own text of ClosestIntersection, DirectLight, AddLight / RandomNumber, Draw(),
+ *       CalculateDOF's blur loops, the rasteriser's Update() cull step, InCuboid, VertexShader, PixelShader,
+ *       Interpolate, Bresenham, ComputePolygonRows, DrawRows, DrawLineSDL's body, DrawPolygon, Draw()'s
+ *       triangle loop and LoadSTL: oracle/extract_ref.py copies those line ranges verbatim into a scratch
+ *       directory, oracle/ref_rt.cpp / ref_raster.cpp compile them against the reference's TestModel.h and
+ *       vendored GLM into oracle/_ref/ (500x500, and the reference's own REALTIME 150x150 build), and
+ *       tests/test_oracle_ref_render.py compares every function with this file BIT FOR BIT on seeded
+ *       inputs (yaw != 0, several lights, soups, soft shadows, supersampling, off-screen spans);
+ *   (2) recorded outputs of (1) for the frames of tests/ref_cases.py (tests/golden/ref_render.json, made by
+ *       tests/golden/make_golden.py), checked by tests/test_golden_ref_render.py wherever the reference is
+ *       absent -- the recipe reproduces the five float-buffer hashes of SURVEY.md Appendix C;
+ *   (3) SURVEY.md Appendix C itself (tests/golden/survey_appendix_c.json, tests/test_oracle_pin.py): hashes
+ *       recorded from the whole unmodified program, the only pin of PutPixelSDL's 8-bit words (its text
+ *       names an SDL type, SDLauxiliary.h:70-81) and of the rasteriser's surface clear;
+ *   (4) TestModel.h + the vendored GLM compiled in place (oracle/_ref/libref_model.so,
+ *       tests/test_oracle_ref_model.py).
+ * Not pinned by any of them: non-square frames (the reference's row stride is SCREEN_HEIGHT, E-1) and
+ * frame sizes other than 500x500 / 150x150 (SCREEN_WIDTH is a compile-time constant of the reference).
  *
  * Arithmetic contract: IEEE binary32, no FMA contraction (build with
  * -ffp-contract=off, no -ffast-math), correctly rounded / and sqrtf, GLM 0.9.7.2 operation order
@@ -319,6 +329,26 @@ static v3 direct_light(const hit_t *i, const float *tris15, int n, const float *
         result2 = add3(result2, result);                                        /* :322, reference quirk E-3 */
     }
     return mul3(result2, ld3(tri + 12));                                        /* :325-326 */
+}
+
+/* One ClosestIntersection call / one DirectLight call, for the function-level pins against the reference's own text
+ * (tests/test_oracle_ref_render.py).  The Intersection record (position, distance, index) is in/out. */
+ORACLE_API int mirt_oracle_closest_intersection(const float *start, const float *dir, const float *tris15, int n,
+                                                float *pos3, float *distance, int *index)
+{
+    hit_t h;
+    h.position = ld3(pos3); h.distance = *distance; h.index = *index;
+    const int any = closest_intersection(ld3(start), ld3(dir), tris15, n, &h);
+    st3(pos3, h.position); *distance = h.distance; *index = h.index;
+    return any;
+}
+
+ORACLE_API void mirt_oracle_direct_light(const float *pos3, float distance, int index, const float *tris15, int n,
+                                         const float *lights7, int nlights, int samples, const float *jitter, float *out3)
+{
+    hit_t h;
+    h.position = ld3(pos3); h.distance = distance; h.index = index;
+    st3(out3, direct_light(&h, tris15, n, lights7, nlights, samples, jitter));
 }
 
 /* PutPixelSDL's colour conversion, raytracer/Source/SDLauxiliary.h:75-80 on an XRGB8888 surface. */
@@ -670,6 +700,8 @@ ORACLE_API void mirt_oracle_rasterise_ex(const float *tris15, const uint8_t *cul
  * blurred colour; border pixels are left alone, or zeroed when clear_border (the rasteriser's Update() painted the whole
  * surface black).  Tap addresses are flat indices as in the reference; a flat index outside the frame is undefined
  * behaviour there and contributes nothing here (documented divergence). */
+static float *g_dof_float_out = NULL;      /* set by mirt_oracle_dof_float only (single-threaded test use) */
+
 ORACLE_API void mirt_oracle_dof(const float *rgb, const float *fd, int W, int H, int K, int y0, int y1, int clear_border,
                                 uint32_t *out_xrgb, int pitch_words)
 {
@@ -696,7 +728,16 @@ ORACLE_API void mirt_oracle_dof(const float *rgb, const float *fd, int W, int H,
                     fin = add3(fin, scale3(c, weighting));
                 }
             out_xrgb[(size_t)y * pitch_words + x] = pack_xrgb(fin);              /* PutPixelSDL :646 */
+            if (g_dof_float_out) st3(g_dof_float_out + 3 * ((size_t)y * W + x), fin);
         }
+}
+
+/* The same with finalColour itself (what the reference hands to PutPixelSDL) stored as floats for interior pixels. */
+ORACLE_API void mirt_oracle_dof_float(const float *rgb, const float *fd, int W, int H, int K, float *out_rgb, uint32_t *scratch_xrgb)
+{
+    g_dof_float_out = out_rgb;
+    mirt_oracle_dof(rgb, fd, W, H, K, 0, H, 0, scratch_xrgb, W);
+    g_dof_float_out = NULL;
 }
 
 /* ------------------------------------------------------------------------------------------ */

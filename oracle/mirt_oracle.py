@@ -59,6 +59,9 @@ class Oracle:
                                                  C.c_int, f32p, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int]
         lib.mirt_oracle_dof.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int]
         lib.mirt_oracle_load_stl.argtypes = [C.c_char_p, C.c_float, f32p, _vp, C.c_int]
+        lib.mirt_oracle_closest_intersection.argtypes = [f32p, f32p, f32p, C.c_int, f32p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        lib.mirt_oracle_direct_light.argtypes = [f32p, C.c_float, C.c_int, f32p, C.c_int, _vp, C.c_int, C.c_int, _vp, f32p]
+        lib.mirt_oracle_dof_float.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, _vp]
         lib.mirt_oracle_load_stl.restype = C.c_int
         for name in ("mat3_inverse", "mat3_mul_vec", "vec_mul_mat3", "normalize", "cross"):
             getattr(lib, "mirt_oracle_" + name).argtypes = [f32p] * (2 if name in ("mat3_inverse", "normalize") else 3)
@@ -127,6 +130,33 @@ class Oracle:
             np.asarray(indirect, np.float32), y0, y1,
             threads, _ptr(out["rgb"]), _ptr(out["index"]), _ptr(out["dist"]), _ptr(out["pos"]), _ptr(out["xrgb"]), W)
         out["nshadow"] = int(ns)
+        return out
+
+    def closest_intersection(self, tris, start, direction, pos=(0, 0, 0), distance=np.finfo(np.float32).max, index=-1):
+        """One ClosestIntersection call on an in/out Intersection record: (any, position, distance, index)."""
+        tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 15)
+        p, d, i = np.asarray(pos, np.float32).copy(), C.c_float(distance), C.c_int(index)
+        any_ = self.lib.mirt_oracle_closest_intersection(np.asarray(start, np.float32), np.asarray(direction, np.float32), tris, len(tris),
+                                                         p, C.byref(d), C.byref(i))
+        return bool(any_), p, np.float32(d.value), i.value
+
+    def direct_light(self, tris, pos, distance, index, lights, samples=1, jitter=None):
+        tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 15)
+        lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 7)
+        jit = None if jitter is None else np.ascontiguousarray(jitter, np.float32)
+        out = np.zeros(3, np.float32)
+        self.lib.mirt_oracle_direct_light(np.asarray(pos, np.float32), float(distance), int(index), tris, len(tris),
+                                          _ptr(lights) if len(lights) else None, len(lights), int(samples), _ptr(jit), out)
+        return out
+
+    def dof_float(self, rgb, fd, K):
+        """CalculateDOF's blur as floats (what the reference hands to PutPixelSDL), interior pixels."""
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        fd = np.ascontiguousarray(fd, np.float32)
+        H, W = fd.shape
+        out = np.zeros((H, W, 3), np.float32)
+        scratch = np.zeros((H, W), np.uint32)
+        self.lib.mirt_oracle_dof_float(rgb.reshape(-1), fd.reshape(-1), W, H, int(K), out.reshape(-1), _ptr(scratch))
         return out
 
     def cull(self, tris, cam_pos, rot9, focal, W, H, flags=3):
