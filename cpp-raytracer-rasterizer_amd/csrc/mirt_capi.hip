@@ -19,7 +19,7 @@
 namespace mirt {
 
 // kernels (rt_kernels.hip, raster_kernels.hip)
-__global__ void k_prep_origin(const float *, int, const float *, OriginRow *, OriginRow *, uint32_t *);
+__global__ void k_prep_origin(const float *, int, const float *, v3, int, OriginRow *, OriginRow *, uint32_t *, unsigned long long *, uint32_t *);
 template <int P> __global__ void k_rt_brute(const RtFrame);
 template <int P> __global__ void k_rt_small(const RtFrame, int);
 __global__ void k_rt_wave(const RtFrame);
@@ -35,15 +35,20 @@ template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile2(const RtTileFrame);
 __global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
 __global__ void k_bin_offsets(const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *);
-struct RtBinnedFrame {
+struct RtTraceFrame {
     RtFrame f;
-    BinSet bins;
-    uint32_t cam_base;
-    uint32_t light_base[MIRT_MAX_LIGHTS];
+    const uint32_t *cam_off;
+    const uint32_t *cam_entries;
+    const GeoRow *geo;
+    const uint32_t *light_off;
+    const TriRow *light_rows;
     int tiles_x;
     int cube_bins;
 };
-template <bool AA> __global__ void k_rt_binned(const RtBinnedFrame);
+template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
+__global__ void k_geo_table(const float *, int, GeoRow *);
+__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, const GeoRow *, int, TriRow *);
+size_t rt_trace_lds_bytes();
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
 __global__ void k_cull(const float *, int, const CullParams, uint8_t *);
 
@@ -84,10 +89,30 @@ struct RtScratch {
     uint32_t *d_pair_keys = nullptr, *d_pair_vals = nullptr, *d_sorted_keys = nullptr;   // unsorted pairs, sorted bin ids
     void *d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
+    uint32_t *d_tmp_vals = nullptr;              // bucket sort: the pairs partitioned by bucket (keys go to d_sorted_keys)
+    uint32_t *d_bucket = nullptr;                // bucket sort: counts | bases (+1) | cursors, cap_buckets each
+    uint32_t cap_buckets = 0;
+    bool bucket_dirty = false;                   // d_bucket may hold counts of a pass whose sort never ran
     uint32_t cap_bins = 0, cap_entries = 0;
     uint64_t bin_key = 0;
     uint32_t bin_entries = 0;                    // pairs of the current binning
     bool bin_key_valid = false;
+};
+
+// The light-cube bins of the binned ray tracer: they depend on the scene and the light positions only, not on the camera,
+// so they are built once per (scene version, light positions, grid) and shared by the frames of both streams.
+struct LightCache {
+    bool valid = false;
+    uint64_t key = 0;
+    OriginRow *d_light_tab = nullptr;            // nl x n origin rows
+    size_t cap_tab = 0;
+    BinFrameDesc *d_frames = nullptr;            // 6 x nl frame descriptors
+    uint32_t *d_off = nullptr;                   // nbins + 1
+    uint32_t cap_bins = 0, nbins = 0;
+    TriRow *d_rows = nullptr;                    // expanded candidates in bin order
+    uint32_t cap_rows = 0, nrows = 0;
+    float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
+    uint32_t *d_counter = nullptr;               // pair counter of the build
 };
 
 struct Ctx {
@@ -111,6 +136,8 @@ struct Ctx {
     float *d_tris = nullptr;
     uint8_t *d_culled = nullptr;
     RtScratch rt[2];                             // per-stream tables of the non-tile ray-trace paths (frames in flight)
+    GeoRow *d_geo = nullptr;                     // n geometry rows (built by mirt_scene_upload)
+    LightCache lc;
     unsigned long long *d_hits = nullptr;        // the hit-counter buffer of the current frame (one of d_hits2)
     unsigned long long *d_hits2[4] = { nullptr, nullptr, nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
     bool hits_clean[4] = { false, false, false, false };   // buffer is all zero (the tile kernel clears the one two frames ahead itself)
@@ -311,6 +338,261 @@ BinFrameDesc make_camera_frame(const mirt_view *view, int y0, int y1, int aa)
     return c;
 }
 
+// ---- binned ray tracing ---------------------------------------------------------------------------------------------
+
+// Makes room for `cap` (bin, triangle) pairs in a stream's pair list, its sorted copy and the sort's scratch.
+int ensure_pairs(RtScratch &S, size_t cap)
+{
+    int r;
+    if ((r = dev_realloc(&S.d_entries, cap)) || (r = dev_realloc(&S.d_pair_keys, cap)) || (r = dev_realloc(&S.d_pair_vals, cap)) ||
+        (r = dev_realloc(&S.d_sorted_keys, cap)) || (r = dev_realloc(&S.d_tmp_vals, cap))) { S.cap_entries = 0; return r; }
+    const size_t need = bin_sort_temp_bytes((uint32_t)cap, 32);
+    if (need == 0) return fail(MIRT_ERR_HIP, "radix sort: cannot size its temporary storage for %zu pairs", cap);
+    if (need > S.sort_temp_bytes) {
+        if (S.d_sort_temp) (void)hipFree(S.d_sort_temp);
+        S.d_sort_temp = nullptr; S.sort_temp_bytes = 0;
+        if (hipMalloc(&S.d_sort_temp, need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "radix sort scratch (%zu bytes)", need);
+        S.sort_temp_bytes = need;
+    }
+    S.cap_entries = (uint32_t)cap;
+    return MIRT_OK;
+}
+
+int key_bits_for(uint32_t nbins)
+{
+    int bits = 1;
+    while ((1u << bits) < nbins && bits < 32) bits++;
+    return bits;
+}
+
+// One binning pass on g.stream: (bin, triangle) pairs of `bs`' frames into S' pair list, ordered by bin into S.d_entries /
+// S.d_sorted_keys, offsets into bin_off.  `counter` (device, zeroed by the caller's previous kernel) receives the pair
+// count.  The list is sized from a count only the device knows: when `fresh` it is read back (4 bytes + one sync of this
+// stream) and the pass repeated if the list was too small; otherwise *npairs, the count of the identical pass before, holds.
+int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow *light_tab, uint32_t *counter, uint32_t *bin_off,
+             bool fresh, uint32_t *npairs)
+{
+    int rc;
+    if (!S.d_entries || !S.cap_entries) {
+        // first capacity of the pair list (grown on demand below); MIRT_BIN_INITIAL_PAIRS lets a test start small
+        static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
+        if ((rc = ensure_pairs(S, initial))) return rc;
+    }
+    // workgroups striding over the (256-triangle chunk, frame) work items: 8 per CU (36 KiB of LDS each, 4 resident; 1 M
+    // triangles at 8K: 4.06 -> 3.53 ms per frame against 3 per CU); MIRT_BIN_WGS overrides
+    static const int bin_wgs = [] { const char *e = getenv("MIRT_BIN_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 16) ? v : 8; }();
+    const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + 255) / 256) * bs.nframes, (long long)g.cu_count * bin_wgs));
+    bs.counters = counter;
+    // order the pairs by bin with the two-level counting sort on the bin id (bin_bucket_sort.hip: k_bin_pairs counts the pairs
+    // per bucket, two more launches sort), or -- when the bins are too many for its LDS histograms, or MIRT_BIN_SORT=rocprim --
+    // with rocPRIM's radix sort + a binary search per bin
+    static const bool force_generic = [] { const char *e = getenv("MIRT_BIN_SORT"); return e && !strcmp(e, "rocprim"); }();
+    const uint32_t nbuckets = bucket_sort_buckets(bs.nbins);
+    const bool bucket_sort = !force_generic && nbuckets <= BUCKET_SORT_MAX_BUCKETS;
+    uint32_t *bcnt = nullptr, *bbase = nullptr, *bcur = nullptr;
+    if (bucket_sort) {
+        if (nbuckets + 1 > S.cap_buckets) {
+            S.cap_buckets = 0;
+            if ((rc = dev_realloc(&S.d_bucket, (size_t)3 * (nbuckets + 1)))) return rc;
+            HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (nbuckets + 1), g.stream));
+            S.cap_buckets = nbuckets + 1;
+            S.bucket_dirty = false;
+        }
+        bcnt = S.d_bucket; bbase = S.d_bucket + S.cap_buckets; bcur = S.d_bucket + 2 * (size_t)S.cap_buckets;
+        bs.bucket_cnt = bcnt; bs.nbuckets = nbuckets; bs.bucket_shift = bucket_sort_shift(bs.nbins);
+    }
+    const size_t bin_lds = bucket_sort ? (size_t)nbuckets * sizeof(uint32_t) : 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        BinPairs pairs = { S.d_pair_keys, S.d_pair_vals, S.cap_entries };
+        bs.entries = S.d_entries; bs.cap_entries = S.cap_entries;
+        if (attempt) HIP_TRY(hipMemsetAsync(counter, 0, 4, g.stream));
+        if (bucket_sort && (attempt || S.bucket_dirty)) HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (size_t)S.cap_buckets, g.stream));
+        S.bucket_dirty = bucket_sort;                        // bucket counts pending until k_bs_local has consumed them
+        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(256), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
+        if (!fresh) break;
+        uint32_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&total, counter, 4, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        *npairs = total;
+        if (total <= S.cap_entries) break;
+        if (attempt == 1) return fail(MIRT_ERR_HIP, "binning produced %u pairs twice with room for %u", total, S.cap_entries);
+        if ((rc = ensure_pairs(S, (size_t)total + total / 8 + 4096))) return rc;
+    }
+#ifdef MIRT_BIN_STATS
+    if (fresh) {
+        uint32_t c[16];
+        (void)hipMemcpy(c, counter, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mirt bin stats] flattened tests=%u max per work item=%u direct items=%u | huge: box valid=%u no box=%u (camera frame %u)\n", c[8], c[9], c[10], c[11], c[12], c[14]);
+        fprintf(stderr, "[mirt bin stats] tris=%d frames=%d  pairs=%u  bins=%u | large items walked=%u level-1 rounds=%u level-2 steps=%u pairs=%u max steps/item=%u items>100 steps=%u\n",
+                g.n, bs.nframes, *npairs, bs.nbins, c[2], c[3], c[4], c[5], c[6], c[7]);
+        (void)hipMemset(counter + 2, 0, 56);
+    }
+#endif
+    if (bucket_sort) {
+        HIP_TRY(bucket_sort_pairs(S.d_pair_keys, S.d_pair_vals, counter, S.cap_entries, *npairs, bs.nbins, S.d_sorted_keys, S.d_tmp_vals,
+                                  bcnt, bbase, bcur, bin_off, S.d_entries, g.cu_count, g.stream));
+        S.bucket_dirty = false;                              // k_bs_local leaves the counts and cursors zero
+        return MIRT_OK;
+    }
+    HIP_TRY(bin_sort_pairs(S.d_sort_temp, S.sort_temp_bytes, S.d_pair_keys, S.d_sorted_keys, S.d_pair_vals, S.d_entries, *npairs, key_bits_for(bs.nbins), g.stream));
+    hipLaunchKernelGGL(k_bin_offsets, dim3((bs.nbins + 1 + 255) / 256), dim3(256), 0, g.stream, S.d_sorted_keys, counter, S.cap_entries, bs.nbins, bin_off);
+    return MIRT_OK;
+}
+
+// The light-cube bins (six faces of B x B bins around every light position) and their expanded rows.  Built on g.stream as a
+// barrier call -- the frames of both streams read the tables -- whenever the scene, a light position or the grid changed.
+int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int nlights, int cube_bins)
+{
+    int rc;
+    LightCache &C = g.lc;
+    uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
+    {
+        auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
+        mix(origins + 3, sizeof(float) * 3 * nlights); mix(&nlights, 4); mix(&g.n, 4); mix(&cube_bins, 4);
+    }
+    if (C.valid && C.key == key) return MIRT_OK;
+    C.valid = false;
+    const int other = (g.stream == g.streams[0]) ? 1 : 0;
+    if (g.in_flight == 2) {                                  // frames of the other stream may still read the old tables
+        HIP_TRY(hipEventRecord(g.ev_cull, g.streams[other]));
+        HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_cull, 0));
+    }
+    const uint32_t per_light = 6u * (uint32_t)(cube_bins * cube_bins), nbins = per_light * (uint32_t)nlights;
+    if ((size_t)nlights * g.n > C.cap_tab) {
+        C.cap_tab = 0;
+        if ((rc = dev_realloc(&C.d_light_tab, (size_t)nlights * g.n))) return rc;
+        C.cap_tab = (size_t)nlights * g.n;
+    }
+    if (nbins + 1 > C.cap_bins) {
+        C.cap_bins = 0;
+        if ((rc = dev_realloc(&C.d_off, (size_t)nbins + 1))) return rc;
+        C.cap_bins = nbins + 1;
+    }
+    if (!C.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_frames), sizeof(BinFrameDesc) * 6 * MIRT_MAX_LIGHTS));
+    if (!C.d_origins) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
+    if (!C.d_counter) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_counter), 64)); HIP_TRY(hipMemset(C.d_counter, 0, 64)); }
+    C.nbins = nbins;
+    C.nrows = 0;
+    if (nlights > 0) {
+        BinFrameDesc frames[6 * MIRT_MAX_LIGHTS];
+        memset(frames, 0, sizeof frames);
+        uint32_t base = 0;
+        for (int k = 0; k < nlights; k++)
+            for (int face = 0; face < 6; face++) {
+                BinFrameDesc &d = frames[k * 6 + face];
+                const int ax = face >> 1;
+                d.P0[ax] = (face & 1) ? -1.0f : 1.0f;         // negD ~ s*e_k + u*e_(k+1) + v*e_(k+2)
+                d.Pu[(ax + 1) % 3] = 1.0f;
+                d.Pv[(ax + 2) % 3] = 1.0f;
+                d.rw[ax] = d.P0[ax]; d.ru[(ax + 1) % 3] = 1.0f; d.rv[(ax + 2) % 3] = 1.0f;   // g = m*(s e_k + u e_k1 + v e_k2)
+                memcpy(d.S, f.lpos[k], 12);                       // light position k (jittered sample with soft shadows)
+                d.dmax = 2.0f;
+                d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / (float)cube_bins; d.dv = 2.0f / (float)cube_bins;
+                d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
+                d.nbu = cube_bins; d.nbv = cube_bins; d.j0 = 0; d.j1 = cube_bins;
+                d.base = base; d.tab = 1 + k;
+                base += (uint32_t)(cube_bins * cube_bins);
+            }
+        HIP_TRY(hipMemcpyAsync(C.d_frames, frames, sizeof(BinFrameDesc) * 6 * nlights, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(C.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
+        hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, nlights), dim3(256), 0, g.stream,
+                           g.d_tris, g.n, C.d_origins, V3(0.0f, 0.0f, 0.0f), 1, (OriginRow *)nullptr, C.d_light_tab, (uint32_t *)nullptr,
+                           (unsigned long long *)nullptr, C.d_counter);
+        BinSet bs;
+        memset(&bs, 0, sizeof bs);
+        bs.frames = C.d_frames; bs.nframes = 6 * nlights; bs.nbins = nbins; bs.bin_off = C.d_off;
+        uint32_t npairs = 0;
+        if ((rc = bin_pass(S, bs, nullptr, C.d_light_tab, C.d_counter, C.d_off, true, &npairs))) return rc;
+        if (npairs > C.cap_rows) {
+            C.cap_rows = 0;
+            if ((rc = dev_realloc(&C.d_rows, (size_t)npairs + npairs / 8 + 1024))) return rc;
+            C.cap_rows = npairs + npairs / 8 + 1024;
+        }
+        C.nrows = npairs;
+        if (npairs)
+            hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((npairs + 255) / 256, 4096u)), dim3(256), 0, g.stream,
+                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.d_geo, g.n, C.d_rows);
+        HIP_TRY(hipGetLastError());
+        S.bin_key_valid = false;                             // the stream's pair list now holds the light pass
+    } else {
+        HIP_TRY(hipMemsetAsync(C.d_off, 0, 4, g.stream));
+    }
+    if (g.in_flight == 2) {                                  // later frames of the other stream wait for the build
+        HIP_TRY(hipEventRecord(g.ev_cull, g.stream));
+        HIP_TRY(hipStreamWaitEvent(g.streams[other], g.ev_cull, 0));
+    }
+    C.key = key;
+    C.valid = true;
+    return MIRT_OK;
+}
+
+// A binned frame: camera origin rows, camera-tile bins (the only per-frame binning), trace.
+int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const float *origins, int nlights, int y0, int y1)
+{
+    int rc;
+    g.stats.mode_used = MIRT_RT_BINNED;
+    // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists and cost more binning; measured
+    // (one light): 100 k triangles 0.37 / 0.47 / 0.92 ms per frame at 64 / 128 / 256, 1 M triangles 5.1 / 3.9 / 4.1 ms.
+    // MIRT_CUBE_BINS=64|128|256 overrides.
+    static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
+    int cube_bins = g.n >= 300000 ? 2 * CUBE_BINS_MIN : CUBE_BINS_MIN;
+    if (cube_override == 64 || cube_override == 128 || cube_override == 256) cube_bins = cube_override;
+
+    k_begin(MIRT_K_BIN);
+    if ((rc = light_cache_ensure(S, f, origins, nlights, cube_bins))) return rc;
+
+    BinSet bs;
+    memset(&bs, 0, sizeof bs);
+    bs.frame0 = make_camera_frame(view, y0, y1, g.aa);
+    bs.frames = nullptr; bs.nframes = 1;
+    bs.nbins = (uint32_t)bs.frame0.nbu * bs.frame0.nbv;
+    if (bs.nbins + 1 > S.cap_bins) {
+        const size_t cap = (size_t)bs.nbins + 1;
+        if ((rc = dev_realloc(&S.d_bin_off, cap))) { S.cap_bins = 0; return rc; }
+        S.cap_bins = (uint32_t)cap;
+        S.bin_key_valid = false;
+    }
+    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 64)); HIP_TRY(hipMemset(S.d_bin_counters, 0, 64)); }
+    bs.bin_off = S.d_bin_off;
+
+    uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
+    {
+        auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
+        mix(view, sizeof *view); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4); mix(&g.aa, 4);
+    }
+    // first kernel of the frame: the camera's origin rows; it also zeroes the hit counters and the pair counter
+    g.hits_clean[g.hits_cur] = false;
+    hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1), dim3(256), 0, g.stream,
+                       g.d_tris, g.n, (const float *)nullptr, V3(origins[0], origins[1], origins[2]), 0, S.d_cam_tab, (OriginRow *)nullptr,
+                       (uint32_t *)nullptr, g.d_hits, S.d_bin_counters);
+    // the pair count is read back (4 bytes + one sync of this stream) only when the inputs that determine it changed
+    const bool fresh = !S.bin_key_valid || S.bin_key != key;
+    if ((rc = bin_pass(S, bs, S.d_cam_tab, nullptr, S.d_bin_counters, S.d_bin_off, fresh, &S.bin_entries))) return rc;
+    S.bin_key = key;
+    S.bin_key_valid = true;
+    k_end(MIRT_K_BIN);
+
+    RtTraceFrame tf;
+    memset(&tf, 0, sizeof tf);
+    tf.f = f;
+    tf.cam_off = S.d_bin_off;
+    tf.cam_entries = S.d_entries;
+    tf.geo = g.d_geo;
+    tf.light_off = g.lc.d_off;
+    tf.light_rows = g.lc.d_rows;
+    tf.tiles_x = bs.frame0.nbu;
+    tf.cube_bins = cube_bins;
+    const int tile_rows = bs.frame0.j1 - bs.frame0.j0;
+    const size_t lds = rt_trace_lds_bytes();
+    k_begin(MIRT_K_TRACE);
+    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace<true>, dim3((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), lds, g.stream, tf);
+    else hipLaunchKernelGGL(k_rt_trace<false>, dim3((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), lds, g.stream, tf);
+    k_end(MIRT_K_TRACE);
+    HIP_TRY(hipGetLastError());
+    call_end();
+    return MIRT_OK;
+}
+
 int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect, int mode,
                int y0, int y1, int row_origin, void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_index, void *d_fd = nullptr,
                void *d_dist = nullptr, void *d_pos = nullptr)
@@ -424,7 +706,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             if ((rc = dev_realloc(&S.d_cam_tab, (size_t)g.n))) return rc;
             S.cam_tab_n = g.n;
         }
-        if (light_positions > S.light_tab_lights || S.light_tab_n != g.n) {
+        if (!binned && (light_positions > S.light_tab_lights || S.light_tab_n != g.n)) {   // (binned frames read the shared light cache)
             S.light_tab_lights = 0;
             if ((rc = dev_realloc(&S.d_light_tab, (size_t)light_positions * g.n))) return rc;
             S.light_tab_lights = light_positions;
@@ -502,17 +784,18 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         return MIRT_OK;
     }
 
+    if (binned) return rt_enqueue_binned(f, view, S, origins, nlights, y0, y1);
+
     HIP_TRY(hipMemcpyAsync(S.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
     g.hits_clean[g.hits_cur] = false;
     HIP_TRY(hipMemcpyAsync(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
 
     k_begin(MIRT_K_PREP);
     hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1 + nlights), dim3(256), 0, g.stream,
-                       g.d_tris, g.n, S.d_origins, S.d_cam_tab, S.d_light_tab, S.d_flags);
+                       g.d_tris, g.n, S.d_origins, V3(0.0f, 0.0f, 0.0f), 0, S.d_cam_tab, S.d_light_tab, S.d_flags, g.d_hits, (uint32_t *)nullptr);
     k_end(MIRT_K_PREP);
 
-    if (!binned && g.aa <= 1 && (long long)view->width * rows <= 4096 && g.n >= 1024) {
+    if (g.aa <= 1 && (long long)view->width * rows <= 4096 && g.n >= 1024) {
         // few rays, many triangles: one wave per ray, lanes over triangles, wavefront min-t reduce
         const long long nrays = (long long)view->width * rows;
         k_begin(MIRT_K_TRACE);
@@ -522,143 +805,12 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         call_end();
         return MIRT_OK;
     }
-    if (!binned) {
-        const size_t lds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
-        k_begin(MIRT_K_TRACE);
-        if (P == 2)
-            hipLaunchKernelGGL(k_rt_brute<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), lds, g.stream, f);
-        else
-            hipLaunchKernelGGL(k_rt_brute<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), lds, g.stream, f);
-        k_end(MIRT_K_TRACE);
-        HIP_TRY(hipGetLastError());
-        call_end();
-        return MIRT_OK;
-    }
-
-    // ---- binned: frame descriptors (camera tiles + six cube faces per light) ----
-    g.stats.mode_used = MIRT_RT_BINNED;
-    BinFrameDesc frames[MAX_BIN_FRAMES];
-    memset(frames, 0, sizeof frames);
-    uint32_t nbins = 0;
-    frames[0] = make_camera_frame(view, y0, y1, g.aa);
-    nbins = (uint32_t)frames[0].nbu * frames[0].nbv;
-    int nframes = 1;
-    // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists and cost more binning; measured
-    // (one light): 100 k triangles 0.37 / 0.47 / 0.92 ms per frame at 64 / 128 / 256, 1 M triangles 5.1 / 3.9 / 4.1 ms.
-    // MIRT_CUBE_BINS=64|128|256 overrides.
-    static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
-    int cube_bins = g.n >= 300000 ? 2 * CUBE_BINS_MIN : CUBE_BINS_MIN;
-    if (cube_override == 64 || cube_override == 128 || cube_override == 256) cube_bins = cube_override;
-    RtBinnedFrame bf;
-    memset(&bf, 0, sizeof bf);
-    for (int k = 0; k < nlights; k++) {
-        bf.light_base[k] = nbins;
-        for (int face = 0; face < 6; face++) {
-            BinFrameDesc &d = frames[nframes++];
-            const int ax = face >> 1;
-            d.P0[ax] = (face & 1) ? -1.0f : 1.0f;         // negD ~ s*e_k + u*e_(k+1) + v*e_(k+2)
-            d.Pu[(ax + 1) % 3] = 1.0f;
-            d.Pv[(ax + 2) % 3] = 1.0f;
-            d.rw[ax] = d.P0[ax]; d.ru[(ax + 1) % 3] = 1.0f; d.rv[(ax + 2) % 3] = 1.0f;   // g = m*(s e_k + u e_k1 + v e_k2)
-            memcpy(d.S, f.lpos[k], 12);                       // light position k (jittered sample with soft shadows)
-            d.dmax = 2.0f;
-            d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / (float)cube_bins; d.dv = 2.0f / (float)cube_bins;
-            d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
-            d.nbu = cube_bins; d.nbv = cube_bins; d.j0 = 0; d.j1 = cube_bins;
-            d.base = nbins; d.tab = 1 + k;
-            nbins += (uint32_t)(cube_bins * cube_bins);
-        }
-    }
-    if (nbins + 1 > S.cap_bins) {
-        const size_t cap = (size_t)nbins + 1;
-        if ((rc = dev_realloc(&S.d_bin_off, cap))) { S.cap_bins = 0; return rc; }
-        S.cap_bins = (uint32_t)cap;
-        S.bin_key_valid = false;
-    }
-    if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * MAX_BIN_FRAMES));
-    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 64)); HIP_TRY(hipMemset(S.d_bin_counters, 0, 64)); }
-    int key_bits = 1;
-    while ((1u << key_bits) < nbins && key_bits < 32) key_bits++;
-    auto ensure_pairs = [&](size_t cap) -> int {           // pair list, its sorted copy and the sort's scratch, all for `cap` pairs
-        int r;
-        if ((r = dev_realloc(&S.d_entries, cap)) || (r = dev_realloc(&S.d_pair_keys, cap)) || (r = dev_realloc(&S.d_pair_vals, cap)) ||
-            (r = dev_realloc(&S.d_sorted_keys, cap))) { S.cap_entries = 0; return r; }
-        const size_t need = bin_sort_temp_bytes((uint32_t)cap, 32);
-        if (need == 0) return fail(MIRT_ERR_HIP, "radix sort: cannot size its temporary storage for %zu pairs", cap);
-        if (need > S.sort_temp_bytes) {
-            if (S.d_sort_temp) (void)hipFree(S.d_sort_temp);
-            S.d_sort_temp = nullptr; S.sort_temp_bytes = 0;
-            if (hipMalloc(&S.d_sort_temp, need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "radix sort scratch (%zu bytes)", need);
-            S.sort_temp_bytes = need;
-        }
-        S.cap_entries = (uint32_t)cap;
-        return MIRT_OK;
-    };
-    if (!S.d_entries || !S.cap_entries) {
-        // first capacity of the pair list (grown on demand below); MIRT_BIN_INITIAL_PAIRS lets a test start small
-        static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
-        if ((rc = ensure_pairs(initial))) return rc;
-    }
-    HIP_TRY(hipMemcpyAsync(S.d_frames, frames, sizeof(BinFrameDesc) * nframes, hipMemcpyHostToDevice, g.stream));
-
-    // workgroups striding over the (256-triangle chunk, frame) work items: 8 per CU (36 KiB of LDS each, 4 resident; 1 M
-    // triangles at 8K: 4.06 -> 3.53 ms per frame against 3 per CU); MIRT_BIN_WGS overrides
-    static const int bin_wgs = [] { const char *e = getenv("MIRT_BIN_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 16) ? v : 8; }();
-    const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + 255) / 256) * nframes, (long long)g.cu_count * bin_wgs));
-
-    uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
-    {
-        auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
-        mix(view, sizeof *view); mix(origins, sizeof(float) * 3 * (1 + nlights)); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4); mix(&cube_bins, 4); mix(&g.aa, 4);
-    }
-
-    BinSet bs;
-    bs.frames = S.d_frames; bs.nframes = nframes; bs.nbins = nbins;
-    bs.bin_off = S.d_bin_off; bs.entries = S.d_entries; bs.cap_entries = S.cap_entries;
-    bs.counters = S.d_bin_counters;
-    k_begin(MIRT_K_BIN);
-    // The pair list is sized from a count only the device knows; it is read back (4 bytes + one sync) only when the
-    // inputs that determine it changed since the last frame, and the pass is repeated if the list was too small.
-    const bool fresh = !S.bin_key_valid || S.bin_key != key;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        BinPairs pairs = { S.d_pair_keys, S.d_pair_vals, S.cap_entries };
-        HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 4, g.stream));
-        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(256), 0, g.stream, g.d_tris, S.d_cam_tab, S.d_light_tab, g.n, bs, pairs);
-        if (!fresh) break;
-        uint32_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, S.d_bin_counters, 4, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        S.bin_entries = total;
-        if (total <= S.cap_entries) break;
-        if (attempt == 1) return fail(MIRT_ERR_HIP, "binning produced %u pairs twice with room for %u", total, S.cap_entries);
-        if ((rc = ensure_pairs((size_t)total + total / 8 + 4096))) return rc;
-        bs.entries = S.d_entries; bs.cap_entries = S.cap_entries;
-    }
-#ifdef MIRT_BIN_STATS
-    if (fresh) {
-        uint32_t c[16];
-        (void)hipMemcpy(c, S.d_bin_counters, 64, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[mirt bin stats] flattened tests=%u max per work item=%u direct items=%u | huge: box valid=%u no box=%u (camera frame %u)\n", c[8], c[9], c[10], c[11], c[12], c[14]);
-        fprintf(stderr, "[mirt bin stats] tris=%d frames=%d  pairs=%u  bins=%u | large items walked=%u level-1 rounds=%u level-2 steps=%u pairs=%u max steps/item=%u items>100 steps=%u\n",
-                g.n, nframes, S.bin_entries, nbins, c[2], c[3], c[4], c[5], c[6], c[7]);
-        (void)hipMemset(S.d_bin_counters + 2, 0, 56);
-    }
-#endif
-    S.bin_key = key;
-    S.bin_key_valid = true;
-    HIP_TRY(bin_sort_pairs(S.d_sort_temp, S.sort_temp_bytes, S.d_pair_keys, S.d_sorted_keys, S.d_pair_vals, S.d_entries, S.bin_entries, key_bits, g.stream));
-    hipLaunchKernelGGL(k_bin_offsets, dim3((nbins + 1 + 255) / 256), dim3(256), 0, g.stream, S.d_sorted_keys, S.d_bin_counters, S.cap_entries, nbins, S.d_bin_off);
-    k_end(MIRT_K_BIN);
-
-    bf.f = f;
-    bf.bins = bs;
-    bf.cam_base = 0;
-    bf.tiles_x = frames[0].nbu;
-    bf.cube_bins = cube_bins;
-    const int tile_rows = frames[0].j1 - frames[0].j0;
+    const size_t lds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
     k_begin(MIRT_K_TRACE);
-    if (f.aa > 1) hipLaunchKernelGGL(k_rt_binned<true>, dim3((bf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), 0, g.stream, bf);
-    else hipLaunchKernelGGL(k_rt_binned<false>, dim3((bf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), 0, g.stream, bf);
+    if (P == 2)
+        hipLaunchKernelGGL(k_rt_brute<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), lds, g.stream, f);
+    else
+        hipLaunchKernelGGL(k_rt_brute<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), lds, g.stream, f);
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
@@ -790,8 +942,10 @@ extern "C" void mirt_shutdown(void)
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
     for (RtScratch &S : g.rt)
         for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_bin_off,
-                         (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp })
+                         (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp, (void *)S.d_tmp_vals, (void *)S.d_bucket })
             if (p) (void)hipFree(p);
+    for (void *p : { (void *)g.d_geo, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
+        if (p) (void)hipFree(p);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos,
                      (void *)g.dof[0].rgb, (void *)g.dof[0].fd, (void *)g.dof[0].xrgb, (void *)g.dof[0].index, (void *)g.dof[0].zinv,
                      (void *)g.dof[1].rgb, (void *)g.dof[1].fd, (void *)g.dof[1].xrgb, (void *)g.dof[1].index, (void *)g.dof[1].zinv })
@@ -851,6 +1005,11 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
     if (culled) HIP_TRY(hipMemcpy(g.d_culled, culled, (size_t)n, hipMemcpyHostToDevice));
     else HIP_TRY(hipMemset(g.d_culled, 0, (size_t)n));
+    if ((rc = dev_realloc(&g.d_geo, (size_t)n))) return rc;
+    hipLaunchKernelGGL(k_geo_table, dim3((n + 255) / 256), dim3(256), 0, g.stream, g.d_tris, n, g.d_geo);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    g.lc.valid = false;
     g.scene_finite = true;
     for (size_t i = 0; i < (size_t)n * 15 && g.scene_finite; i++)
         if (!(fabsf(tris15[i]) < 1.0e8f)) g.scene_finite = false;   // generous: |coord| < 1e8 keeps cross products < 1e18

@@ -115,6 +115,8 @@ struct BinLargeSink {
     uint32_t *s_valid;            // LDS: slots [0, *s_valid) hold pairs (the step that did not fit any more lowers it)
     uint32_t *g_count;            // the global list's length
     BinPairs out;
+    uint32_t *bucket_cnt;         // nullable: the sort's pairs-per-bucket counters (pairs that bypass the LDS buffer count here)
+    int bucket_shift;
 };
 
 // Walks one large item (wave-uniform `u`) through the three levels and emits its pairs.
@@ -168,6 +170,7 @@ __device__ __forceinline__ void bin_walk_large(const BinItem &u, uint32_t utri, 
                     }
                     at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
                     if (pass2 && at0 + rank < sink.out.cap) { sink.out.keys[at0 + rank] = key; sink.out.vals[at0 + rank] = utri; }
+                    if (pass2 && sink.bucket_cnt) atomicAdd(&sink.bucket_cnt[key >> sink.bucket_shift], 1u);
                 }
             }
         }
@@ -190,6 +193,8 @@ struct BinDirect {
 __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
                                                    const OriginRow *__restrict__ light_tab, int n, BinSet bs, BinPairs out)
 {
+    // pairs per bucket (bin >> bucket_shift) for the sort that follows (bin_bucket_sort.hip): bs.bucket_cnt != NULL
+    extern __shared__ uint32_t s_bucket[];
     __shared__ uint32_t s_keys[BIN_PAIR_BUF], s_vals[BIN_PAIR_BUF];
     __shared__ BinDirect s_item[256];
     __shared__ uint32_t s_org[256];                   // i_lo | j_lo << 16 of a direct item's box
@@ -200,6 +205,8 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunks = (n + 255) / 256, nwork = nchunks * bs.nframes;
     if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
+    if (bs.bucket_cnt)
+        for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += 256) s_bucket[b] = 0u;
 
     // hands the staged pairs over to the global list (called by all threads)
     auto flush = [&]() {
@@ -211,8 +218,14 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         for (uint32_t i = threadIdx.x; i < staged; i += 256) {
             const uint32_t at = base + i;
             if (at < out.cap) { out.keys[at] = s_keys[i]; out.vals[at] = s_vals[i]; }
+            if (bs.bucket_cnt) atomicAdd(&s_bucket[s_keys[i] >> bs.bucket_shift], 1u);
         }
         __syncthreads();
+        if (bs.bucket_cnt && staged)
+            for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += 256) {
+                const uint32_t c = s_bucket[b];
+                if (c) { atomicAdd(&bs.bucket_cnt[b], c); s_bucket[b] = 0u; }
+            }
         if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
         __syncthreads();
     };
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
     for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
         const int chunk = w / bs.nframes, frame = w - chunk * bs.nframes;
         const uint32_t tri0 = (uint32_t)chunk * 256u, tri = tri0 + threadIdx.x;
-        const BinFrameDesc &fr = bs.frames[frame];
+        const BinFrameDesc fr = bs.frames ? bs.frames[frame] : bs.frame0;
         BinFrameGrid gr;
         gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base;
         gr.cells_x = (gr.nbu + BIN_L0 - 1) / BIN_L0; gr.cy0 = gr.fj0 / BIN_L0;
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         // ---- huge items: the wave walks them one at a time, pairs into the same LDS buffer ----
         __syncthreads();                              // no flattened round (which counts on its 256 free slots) is still appending
         {
-            BinLargeSink sink = { s_keys, s_vals, &s_fill, &s_valid, &bs.counters[0], out };
+            BinLargeSink sink = { s_keys, s_vals, &s_fill, &s_valid, &bs.counters[0], out, bs.bucket_cnt, bs.bucket_shift };
             for (unsigned long long ml = __ballot(kind == 2); ml;) {
                 const int src = __builtin_ctzll(ml);
                 ml &= ml - 1ull;
@@ -414,159 +427,5 @@ __global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict_
     }
     bin_off[b] = lo;
 }
-
-// ---- k_rt_binned: fused primary + shadow + shade + resolve over the binned candidates ---------------
-//
-// Workgroup = 256 threads = 4 wave64; each wave owns one 8x8-pixel tile (= one camera bin), the block a
-// 16x16 area.  Primary rays: the tile's candidate rows are gathered 64 at a time into the wave's LDS slice
-// (one lane loads one candidate's 48-byte origin row), then every lane walks them with broadcast reads -- the
-// same inner loop as brute force.  Shadow rays leave the light in incoherent directions, so every lane walks
-// the list of its own light-cube bin straight from global memory (the tables live in L2 / Infinity Cache).
-struct RtBinnedFrame {
-    RtFrame f;
-    BinSet bins;
-    uint32_t cam_base;                       // bin base of the camera frame
-    uint32_t light_base[MIRT_MAX_LIGHTS];    // bin base of face 0 of each light
-    int tiles_x;                             // camera bins per row (nbu)
-    int cube_bins;                           // light-cube bins per face side
-};
-
-// order-independent form of the reference's sequential ">=" update (raytracer.cpp:243-247):
-// smaller distance wins, equal distance -> larger triangle index wins
-__device__ __forceinline__ bool closer(float dist, int idx, float best_d, int best_i)
-{
-    return dist < best_d || (dist == best_d && idx > best_i);
-}
-
-template <bool AA>
-__global__ __launch_bounds__(256) void k_rt_binned(const RtBinnedFrame bf)
-{
-    const RtFrame &f = bf.f;
-    __shared__ __attribute__((aligned(16))) float4 s_rows[4][64 * 3];
-    __shared__ uint32_t s_idx[4][64];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx = (int)blockIdx.x * 2 + (wave & 1);
-    const int ty = f.y0 / BIN_TILE + (int)blockIdx.y * 2 + (wave >> 1);
-    const int x = tx * BIN_TILE + (lane & 7), y = ty * BIN_TILE + (lane >> 3);
-    const bool tile_ok = tx < bf.tiles_x && ty * BIN_TILE < f.y1;
-    const bool ok = tile_ok && x < f.W && y >= f.y0 && y < f.y1;
-    if (!tile_ok) return;                                  // wave-uniform
-    const v3 cam = ld3(f.cam);
-    const int rs = AA ? f.aa : 1;                          // realSamples (:549-554); compile-time 1 without supersampling
-
-    const uint32_t cbin = bf.cam_base + (uint32_t)ty * bf.tiles_x + tx;
-    const uint32_t cbeg = bf.bins.bin_off[cbin], cend = bf.bins.bin_off[cbin + 1];
-
-    float best_d = FLT_MAX;                                // Update() reset (:335-339), once per frame
-    int best_i = -1;
-    v3 pos = V3(0.0f, 0.0f, 0.0f), avg = V3(0.0f, 0.0f, 0.0f);
-    unsigned ntests = 0;
-
-    float y1 = aa_start(y, rs);                            // :566-569
-    for (int z = 0; z < rs; z++) {
-        float x1 = aa_start(x, rs);                        // :573-576
-        for (int z2 = 0; z2 < rs; z2++) {
-            // d = (x1 - W/2, y1 - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
-            const v3 d = V3(x1 - (float)f.W / 2.0f, y1 - (float)f.H / 2.0f, f.focal);
-            const v3 nd = neg3(mat3_mul_vec(f.rot, d));
-            // closest hit of THIS sub-ray among the tile's candidates (order-independent: min distance, max index) ...
-            float sd = FLT_MAX;
-            int si = -1;
-            v3 sp = V3(0.0f, 0.0f, 0.0f);
-            if (ok) ntests += cend - cbeg;
-            for (uint32_t base = cbeg; base < cend; base += 64) {
-                const int cnt = (int)min(64u, cend - base);
-                if (lane < cnt) {
-                    const uint32_t idx = bf.bins.entries[base + lane];
-                    const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
-                    s_idx[wave][lane] = idx;
-                    s_rows[wave][3 * lane] = src[0];
-                    s_rows[wave][3 * lane + 1] = src[1];
-                    s_rows[wave][3 * lane + 2] = src[2];
-                }
-                // wave-private LDS slice: the wave's own writes are visible to it after the LDS counter drains
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-                for (int j = 0; j < cnt; j++) {
-                    const float4 r0 = s_rows[wave][3 * j], r1 = s_rows[wave][3 * j + 1], r2 = s_rows[wave][3 * j + 2];
-                    const TestDots td = test_dots(r0, r1, r2, nd);
-                    if (maybe_hit(td)) {
-                        const int idx = (int)s_idx[wave][j];
-                        v3 hp;
-                        float dist;
-                        if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, cam, &hp, &dist))
-                            if (closer(dist, idx, sd, si)) { sd = dist; si = idx; sp = hp; }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            // ... merged into the pixel's running record exactly as the sequential `>=` sweep would (:243): the
-            // sub-ray's best replaces the record when it is at least as close (a later sub-ray wins exact ties)
-            const bool any = si >= 0;                      // ClosestIntersection's return value
-            if (any && best_d >= sd) { best_d = sd; best_i = si; pos = sp; }
-
-            const bool hit = ok && any;
-            count_hits(f, (unsigned long long)__popcll(__ballot(hit)));
-            if (hit) {
-                const float *t = f.tris15 + (size_t)15 * best_i;
-                const v3 nDir = normalize3(ld3(t + 9));            // (:300)
-                const v3 tcol = ld3(t + 12);
-                v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
-                for (int k = 0; k < f.nlights; k++) {
-                    const v3 L = ld3(f.lpos[k]);
-                    v3 rd;
-                    float r;
-                    v3 D = light_term(f, k, pos, nDir, &rd, &r);
-                    const float thr = r * 0.99f;                   // (:313)
-                    const uint32_t bin = cube_bin_of(rd, bf.light_base[k], bf.cube_bins);
-                    const uint32_t beg = bf.bins.bin_off[bin], end = bf.bins.bin_off[bin + 1];
-                    const OriginRow *tab = f.light_tab + (size_t)k * f.n;
-                    uint32_t e = beg;
-                    for (; e < end; e++) {
-                        const uint32_t idx = bf.bins.entries[e];
-                        const float4 *src = reinterpret_cast<const float4 *>(tab + idx);
-                        const float4 r0 = src[0], r1 = src[1], r2 = src[2];
-                        const TestDots td = test_dots(r0, r1, r2, rd);   // negD = rDir (:310, :229)
-                        if (maybe_hit(td)) {
-                            v3 hp;
-                            float dist;
-                            if (exact_hit(td, r0.w, f.tris15 + (size_t)15 * idx, L, &hp, &dist) && dist < thr) {
-                                D = V3(0.0f, 0.0f, 0.0f);          // occluded (:313-314); any-hit is exact
-                                e++;
-                                break;
-                            }
-                        }
-                    }
-                    ntests += e - beg;
-                    result = add3(result, D);                      // (:319)
-                    if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
-                }
-                const v3 Dl = mul3(result2, tcol);                 // (:325-326)
-                const v3 T = add3(Dl, ld3(f.indirect));            // (:584-586)
-                avg = add3(avg, mul3(tcol, T));                    // (:587-591)
-                x1 += aa_step(rs);                                 // (:593) only after a hit
-            }
-        }
-        y1 += aa_step(rs);                                         // (:596)
-    }
-    count_tests(f, ntests);
-    if (!ok) return;
-    avg = div3s(avg, (float)(rs * rs));                            // (:599)
-    const size_t px = (size_t)y * f.W + x;
-    if (f.rgb) st3(f.rgb + 3 * px, avg);
-    if (f.index) f.index[px] = best_i;
-    if (f.fd) f.fd[px] = best_i >= 0 ? best_d - f.focal_plane : 0.0f;          // focalDistances (:248-249)
-    store_intersection(f, px, best_i, best_d, pos);
-    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)            // (:618-620)
-        f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
-}
-
-template __global__ void k_rt_binned<false>(const RtBinnedFrame);
-template __global__ void k_rt_binned<true>(const RtBinnedFrame);
 
 }  // namespace mirt

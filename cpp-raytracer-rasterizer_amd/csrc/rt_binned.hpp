@@ -44,14 +44,25 @@ struct BinFrameDesc {
     int tab;                     // origin table: 0 = camera, 1 + k = light k
 };
 
+// Geometry row of a triangle: {v0.xyz, e1.x | e1.yz, e2.xy | e2.z, 0, 0, 0} -- what the accept path needs to rebuild the hit
+// point (raytracer.cpp:216-217, :241).  One per triangle (k_geo_table, rt_trace.hip).
+struct GeoRow { float4 g0, g1, g2; };
+// A shadow-ray candidate expanded in light-cube bin order: origin row of the triangle for that light + geometry row.
+struct TriRow { OriginRow o; GeoRow g; };
+static_assert(sizeof(TriRow) == 96, "expanded row must be 96 bytes");
+
 struct BinSet {
-    const BinFrameDesc *frames;   // device array
+    const BinFrameDesc *frames;   // device array of nframes descriptors, or NULL: the single frame `frame0` below
+    BinFrameDesc frame0;          // the camera frame travels as a kernel argument (no copy per frame)
     int nframes;
     uint32_t nbins;               // total bins over all frames
     uint32_t *bin_off;            // nbins + 1: first entry of every bin (bin_off[nbins] = total entries), k_bin_offsets
     uint32_t *entries;            // candidate triangle indices ordered by bin (the sorted pair values)
     uint32_t cap_entries;
     uint32_t *counters;           // [0] pairs produced by k_bin_pairs (may exceed the capacity: then the frame is redone)
+    uint32_t *bucket_cnt;         // nullable: pairs per bucket = bin >> bucket_shift, for the bucket sort (bin_bucket_sort.hip)
+    uint32_t nbuckets;
+    int bucket_shift;
 };
 
 // The unsorted (bin, triangle) pair list k_bin_pairs writes and bin_sort.hip orders by bin.

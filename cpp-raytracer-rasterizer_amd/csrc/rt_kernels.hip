@@ -12,22 +12,30 @@
 namespace mirt {
 
 // ---- k_prep_origin: origin tables for the camera and every light --------------------------------------
-// grid.y = 1 + nlights (0 = camera), one thread per triangle.  Also raises *unsafe when an entry is outside
-// the pre-reject filter's proven range (then the trace kernels skip the filter).
+// grid.y = number of origins to build starting at origin o0 (0 = camera, 1 + k = light position k), one thread per
+// triangle.  Also raises *unsafe when an entry is outside the pre-reject filter's proven range (then the trace kernels
+// skip the filter), and -- being the first kernel of a frame -- zeroes the frame's hit counters and the binning pass's
+// pair counter (both nullable), which saves a memset node each.
 __global__ __launch_bounds__(256) void k_prep_origin(const float *__restrict__ tris15, int n,
-                                                     const float *__restrict__ origins /* (1+nl) x 3 */,
+                                                     const float *__restrict__ origins /* (1+nl) x 3, or NULL: origin0 */, v3 origin0, int o0,
                                                      OriginRow *__restrict__ cam_tab,
                                                      OriginRow *__restrict__ light_tab,
-                                                     uint32_t *__restrict__ unsafe)
+                                                     uint32_t *__restrict__ unsafe,
+                                                     unsigned long long *__restrict__ zero_hits, uint32_t *__restrict__ zero_counter)
 {
+    if (blockIdx.y == 0 && blockIdx.x == 0) {
+        if (zero_hits)
+            for (int g = threadIdx.x; g < HIT_SHARDS * HIT_SHARD_STRIDE; g += blockDim.x) zero_hits[g] = 0ull;
+        if (zero_counter && threadIdx.x == 0) *zero_counter = 0u;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int o = blockIdx.y;
+    const int o = o0 + (int)blockIdx.y;
     if (i >= n) return;
-    const v3 S = ld3(origins + 3 * o);
+    const v3 S = origins ? ld3(origins + 3 * o) : origin0;
     const OriginRow r = make_origin_row(tris15 + (size_t)15 * i, S);
     OriginRow *dst = (o == 0) ? cam_tab : light_tab + (size_t)(o - 1) * n;
     dst[i] = r;
-    if (!origin_row_safe(r)) atomicOr(unsafe, 1u);
+    if (unsafe && !origin_row_safe(r)) atomicOr(unsafe, 1u);
 }
 
 // ---- k_rt_brute: fused primary + shadow + shade + resolve, every ray tests every triangle ------------
