@@ -44,8 +44,9 @@ struct RtTraceFrame {
     const TriRow *light_rows;
     int tiles_x;
     int cube_bins;
+    int cam_shells;
 };
-template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
+template <bool AA, bool FLAT> __global__ void k_rt_trace(const RtTraceFrame);
 __global__ void k_geo_table(const float *, int, GeoRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, const GeoRow *, int, TriRow *);
 size_t rt_trace_lds_bytes();
@@ -137,6 +138,7 @@ struct Ctx {
     uint8_t *d_culled = nullptr;
     RtScratch rt[2];                             // per-stream tables of the non-tile ray-trace paths (frames in flight)
     GeoRow *d_geo = nullptr;                     // n geometry rows (built by mirt_scene_upload)
+    float bbox_lo[3] = { 0, 0, 0 }, bbox_hi[3] = { 0, 0, 0 };   // the scene's bounding box (host side, mirt_scene_upload)
     LightCache lc;
     unsigned long long *d_hits = nullptr;        // the hit-counter buffer of the current frame (one of d_hits2)
     unsigned long long *d_hits2[4] = { nullptr, nullptr, nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
@@ -531,11 +533,12 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
 {
     int rc;
     g.stats.mode_used = MIRT_RT_BINNED;
-    // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists and cost more binning; measured
-    // (one light): 100 k triangles 0.37 / 0.47 / 0.92 ms per frame at 64 / 128 / 256, 1 M triangles 5.1 / 3.9 / 4.1 ms.
-    // MIRT_CUBE_BINS=64|128|256 overrides.
+    // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists; the bins are built once per (scene,
+    // lights), not per frame, so what they cost is memory (96 bytes per (bin, triangle) pair) and the build when a light
+    // moves.  Measured on the 100 k soup at 1080p (trace kernel): 64: 153 us, 128: 125 us, 256: 105 us.  MIRT_CUBE_BINS=64|128|256
+    // overrides.
     static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
-    int cube_bins = g.n >= 300000 ? 2 * CUBE_BINS_MIN : CUBE_BINS_MIN;
+    int cube_bins = g.n < 2000 ? CUBE_BINS_MIN : (g.n < 20000 ? 2 * CUBE_BINS_MIN : 4 * CUBE_BINS_MIN);
     if (cube_override == 64 || cube_override == 128 || cube_override == 256) cube_bins = cube_override;
 
     k_begin(MIRT_K_BIN);
@@ -545,7 +548,26 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     memset(&bs, 0, sizeof bs);
     bs.frame0 = make_camera_frame(view, y0, y1, g.aa);
     bs.frames = nullptr; bs.nframes = 1;
-    bs.nbins = (uint32_t)bs.frame0.nbu * bs.frame0.nbv;
+    {
+        // depth shells: the tiles' lists come out of the sort roughly front to back (key = bin * shells + shell of the
+        // candidate's `near` bound, uniform steps between the nearest and the farthest point of the scene's box)
+        static const int shells_env = [] { const char *e = getenv("MIRT_CAM_SHELLS"); return e ? atoi(e) : 0; }();
+        const long long tiles = (long long)bs.frame0.nbu * bs.frame0.nbv;
+        int ns = (int)std::min<long long>(8, std::max<long long>(1, (4ll << 20) / std::max<long long>(tiles, 1)));
+        if (shells_env >= 1 && shells_env <= 64) ns = shells_env;
+        double dn = 0.0, df = 0.0;
+        for (int c = 0; c < 3; c++) {
+            const double p = view->pos[c], lo = g.bbox_lo[c], hi = g.bbox_hi[c];
+            const double near = p < lo ? lo - p : (p > hi ? p - hi : 0.0), far = std::max(std::fabs(p - lo), std::fabs(p - hi));
+            dn += near * near; df += far * far;
+        }
+        dn = std::sqrt(dn); df = std::sqrt(df);
+        const bool okr = std::isfinite(dn) && std::isfinite(df) && df > dn;
+        bs.frame0.nshell = okr ? ns : 1;
+        bs.frame0.shell_d0 = (float)dn;
+        bs.frame0.shell_iw = okr ? (float)(ns / (df - dn)) : 0.0f;
+    }
+    bs.nbins = (uint32_t)bs.frame0.nbu * bs.frame0.nbv * (uint32_t)bs.frame0.nshell;
     if (bs.nbins + 1 > S.cap_bins) {
         const size_t cap = (size_t)bs.nbins + 1;
         if ((rc = dev_realloc(&S.d_bin_off, cap))) { S.cap_bins = 0; return rc; }
@@ -582,11 +604,16 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.light_rows = g.lc.d_rows;
     tf.tiles_x = bs.frame0.nbu;
     tf.cube_bins = cube_bins;
+    tf.cam_shells = bs.frame0.nshell;
     const int tile_rows = bs.frame0.j1 - bs.frame0.j0;
     const size_t lds = rt_trace_lds_bytes();
     k_begin(MIRT_K_TRACE);
-    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace<true>, dim3((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), lds, g.stream, tf);
-    else hipLaunchKernelGGL(k_rt_trace<false>, dim3((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2), dim3(256), lds, g.stream, tf);
+    static const bool flat = [] { const char *e = getenv("MIRT_SHADOW"); return e && !strcmp(e, "flat"); }();
+    const dim3 tgrid((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2);
+    if (f.aa > 1 && flat) hipLaunchKernelGGL((k_rt_trace<true, true>), tgrid, dim3(256), lds, g.stream, tf);
+    else if (f.aa > 1) hipLaunchKernelGGL((k_rt_trace<true, false>), tgrid, dim3(256), lds, g.stream, tf);
+    else if (flat) hipLaunchKernelGGL((k_rt_trace<false, true>), tgrid, dim3(256), lds, g.stream, tf);
+    else hipLaunchKernelGGL((k_rt_trace<false, false>), tgrid, dim3(256), lds, g.stream, tf);
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
@@ -1013,6 +1040,12 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     g.scene_finite = true;
     for (size_t i = 0; i < (size_t)n * 15 && g.scene_finite; i++)
         if (!(fabsf(tris15[i]) < 1.0e8f)) g.scene_finite = false;   // generous: |coord| < 1e8 keeps cross products < 1e18
+    for (int c = 0; c < 3; c++) { g.bbox_lo[c] = INFINITY; g.bbox_hi[c] = -INFINITY; }
+    for (size_t t = 0; t < (size_t)n; t++)
+        for (int v = 0; v < 9; v++) {
+            const float x = tris15[t * 15 + v];
+            g.bbox_lo[v % 3] = fminf(g.bbox_lo[v % 3], x); g.bbox_hi[v % 3] = fmaxf(g.bbox_hi[v % 3], x);
+        }
     g.n = n;
     g.scene_version++;
     return MIRT_OK;

@@ -102,7 +102,7 @@ __device__ __forceinline__ bool bin_jointly_empty(const BinLin (&G)[4], float u0
     return empty;
 }
 
-struct BinFrameGrid { int nbu, fj0, fj1, cells_x, cy0, ncell; uint32_t fbase; };
+struct BinFrameGrid { int nbu, fj0, fj1, cells_x, cy0, ncell; uint32_t fbase, nshell; };
 
 constexpr int BIN_PAIR_BUF = 2048;                    // pairs a workgroup stages in LDS between flushes (16 KiB)
 constexpr int BIN_DIRECT_SIDE = 32;                   // boxes up to 32 x 32 bins are tested bin by bin, flattened over the workgroup
@@ -121,7 +121,7 @@ struct BinLargeSink {
 
 // Walks one large item (wave-uniform `u`) through the three levels and emits its pairs.
 // `cells0` = the owner lane's level-0 verdicts for the first 64 cells (wave-uniform).
-__device__ __forceinline__ void bin_walk_large(const BinItem &u, uint32_t utri, const BinFrameGrid &gr, int lane,
+__device__ __forceinline__ void bin_walk_large(const BinItem &u, uint32_t utri, uint32_t ushell, const BinFrameGrid &gr, int lane,
                                                const BinLargeSink &sink, unsigned long long cells0)
 {
 #ifdef MIRT_BIN_STATS
@@ -157,7 +157,7 @@ __device__ __forceinline__ void bin_walk_large(const BinItem &u, uint32_t utri, 
 #endif
                 if (!m2) continue;
                 const uint32_t np = (uint32_t)__popcll(m2), rank = (uint32_t)__popcll(m2 & ((1ull << lane) - 1ull));
-                const uint32_t key = gr.fbase + (uint32_t)j * gr.nbu + i;
+                const uint32_t key = (gr.fbase + (uint32_t)j * gr.nbu + i) * gr.nshell + ushell;
                 uint32_t at0 = 0;
                 if (lane == 0) at0 = atomicAdd(sink.s_fill, np);
                 at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         const uint32_t tri0 = (uint32_t)chunk * 256u, tri = tri0 + threadIdx.x;
         const BinFrameDesc fr = bs.frames ? bs.frames[frame] : bs.frame0;
         BinFrameGrid gr;
-        gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base;
+        gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base; gr.nshell = (uint32_t)max(fr.nshell, 1);
         gr.cells_x = (gr.nbu + BIN_L0 - 1) / BIN_L0; gr.cy0 = gr.fj0 / BIN_L0;
         gr.ncell = gr.cells_x * ((gr.fj1 + BIN_L0 - 1) / BIN_L0 - gr.cy0);
         const int nbu = gr.nbu, fj0 = gr.fj0, fj1 = gr.fj1;
@@ -247,8 +247,10 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
 #endif
         int i_lo = 0, i_hi = -1, j_lo = 0, j_hi = -1;
         unsigned long long cells = 0;                     // huge items: level-0 cells (first 64) that may hold a hit
+        uint32_t shell = 0;                               // depth shell of the triangle in this frame (orders the bins' lists)
         if (tri < (uint32_t)n && fj1 > fj0) {
             const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
+            shell = bin_shell_of(fr, row.r1.w);
             TriBinFns t = make_bin_fns(row, fr);
             add_bbox(t, tris15 + (size_t)15 * tri, fr);
 #ifdef MIRT_BIN_STATS
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
             d.box = make_float4(it.lou, it.hiu, it.lov, it.hiv);
             s_item[threadIdx.x] = d;
             s_org[threadIdx.x] = (uint32_t)i_lo | ((uint32_t)j_lo << 16);
-            s_ni[threadIdx.x] = ni;
+            s_ni[threadIdx.x] = ni | (shell << 8);
         }
         __syncthreads();
         const uint32_t t0w = s_wave[0], t1w = s_wave[1], t2w = s_wave[2], t3w = s_wave[3];
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
                     const uint32_t mid = (lo + hi) >> 1;
                     if (s_pre[mid] <= t) lo = mid; else hi = mid;
                 }
-                const uint32_t b = t - s_pre[lo], wi = s_ni[lo], org = s_org[lo];
+                const uint32_t nis = s_ni[lo], wi = nis & 0xFFu, sh = nis >> 8;
+                const uint32_t b = t - s_pre[lo], org = s_org[lo];
                 const uint32_t recip = 65536u / wi + 1u;             // b / wi == (b * recip) >> 16 for b < 1024, wi <= 32
                 const uint32_t dj = (b * recip) >> 16, di = b - dj * wi;
                 const int i = (int)(org & 0xFFFFu) + (int)di, j = (int)(org >> 16) + (int)dj;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
                        (__builtin_fmaf(FJ, d.Bv.z, __builtin_fmaf(FI, d.Bu.z, d.A2.z)) >= 0.0f) &&
                        (__builtin_fmaf(FJ, d.Bv.w, __builtin_fmaf(FI, d.Bu.w, d.A2.w)) >= 0.0f) &&
                        (FI + 1.0f >= d.box.x) && (FI <= d.box.y) && (FJ + 1.0f >= d.box.z) && (FJ <= d.box.w);   // = cell_may_hit(.., A2, i, j, 1)
-                key = gr.fbase + (uint32_t)j * (uint32_t)nbu + (uint32_t)i;
+                key = (gr.fbase + (uint32_t)j * (uint32_t)nbu + (uint32_t)i) * gr.nshell + sh;
                 val = tri0 + lo;
             }
             const unsigned long long m = __ballot(pass);
@@ -405,8 +408,9 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
                 }
                 u.lou = bcastf(it.lou, src); u.hiu = bcastf(it.hiu, src); u.lov = bcastf(it.lov, src); u.hiv = bcastf(it.hiv, src);
                 const uint32_t utri = (uint32_t)__builtin_amdgcn_readlane((int)tri, src);
+                const uint32_t ushell = (uint32_t)__builtin_amdgcn_readlane((int)shell, src);
                 const unsigned long long ucells = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cells >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)cells, src);
-                bin_walk_large(u, utri, gr, lane, sink, ucells);
+                bin_walk_large(u, utri, ushell, gr, lane, sink, ucells);
             }
         }
     }

@@ -42,7 +42,19 @@ struct BinFrameDesc {
     int j0, j1;                  // rows of bins to build: [j0, j1)
     uint32_t base;               // index of this frame's bin (0,0) in the global bin arrays
     int tab;                     // origin table: 0 = camera, 1 + k = light k
+    // Depth shells: a bin's list is ordered front to back in `nshell` coarse steps of the candidates' `near` bound (origin
+    // row r1.w) -- sort key = bin * nshell + shell.  Purely an ordering: consumers skip candidates by their own `near`, so no
+    // result depends on it (nshell = 1: unordered).
+    int nshell;
+    float shell_d0, shell_iw;    // shell = clamp((int)((near - shell_d0) * shell_iw), 0, nshell - 1)
 };
+
+__device__ __forceinline__ uint32_t bin_shell_of(const BinFrameDesc &fr, float near)
+{
+    if (fr.nshell <= 1) return 0u;
+    const float s = (near - fr.shell_d0) * fr.shell_iw;
+    return (uint32_t)min(max((int)s, 0), fr.nshell - 1);         // NaN converts to 0
+}
 
 // Geometry row of a triangle: {v0.xyz, e1.x | e1.yz, e2.xy | e2.z, 0, 0, 0} -- what the accept path needs to rebuild the hit
 // point (raytracer.cpp:216-217, :241).  One per triangle (k_geo_table, rt_trace.hip).

@@ -13,7 +13,8 @@ namespace mirt {
 // depend on the ray direction is hoisted into 12 floats per triangle (same operands,
 // same operations => same bits as recomputing them per ray):
 //   row0 = { e1e2.x, e1e2.y, e1e2.z, e1e2b }    e1e2 = cross(e1,e2), e1e2b = dot(e1e2, b)   (:225,:231)
-//   row1 = { be2.x,  be2.y,  be2.z,  0 }        be2  = cross(b, e2), b = S - v0              (:218,:226)
+//   row1 = { be2.x,  be2.y,  be2.z,  near }     be2  = cross(b, e2), b = S - v0              (:218,:226)
+//            near = a conservative LOWER bound of the distance from S to any hit point on the triangle (see origin_near)
 //   row2 = { e1b.x,  e1b.y,  e1b.z,  0 }        e1b  = cross(e1, b)                          (:227)
 // 48 bytes per triangle, read as three 16-byte LDS broadcasts per test.
 struct OriginRow { float4 r0, r1, r2; };
@@ -26,6 +27,19 @@ constexpr int RT_CHUNK_ROWS = 1024;
 // filter's proof to hold (keeps every dot product finite); scenes beyond it take the exact-only path.
 #define MIRT_SAFE_MAG 1.0e18f
 
+// A lower bound of glm::distance(S, pos) for every hit point `pos` the reference can compute on this triangle
+// (raytracer.cpp:241-242): pos lies in the triangle up to the rounding of v0 + u*e1 + v*e2, so its distance from S is at
+// least |c - S| - R for the sphere (c, R) around the vertices; the bound is lowered by 2^-10 of (|c - S| + R) + 1e-6,
+// thousands of times the rounding of either side.  Only ever used to SKIP candidates that cannot beat a closer record
+// (primary rays) or cannot lie before the shaded point (shadow rays); NaN / Inf never skip (comparisons are `near > x`).
+MIRT_HD float origin_near(v3 v0, v3 v1, v3 v2, v3 S)
+{
+    const v3 c = V3((v0.x + v1.x + v2.x) * (1.0f / 3.0f), (v0.y + v1.y + v2.y) * (1.0f / 3.0f), (v0.z + v1.z + v2.z) * (1.0f / 3.0f));
+    const float R = sqrtf(fmaxf(fmaxf(dot3(sub3(v0, c), sub3(v0, c)), dot3(sub3(v1, c), sub3(v1, c))), dot3(sub3(v2, c), sub3(v2, c))));
+    const float dc = sqrtf(dot3(sub3(c, S), sub3(c, S)));
+    return (dc - R) - (0.0009765625f * (dc + R) + 1.0e-6f);
+}
+
 MIRT_HD OriginRow make_origin_row(const float *t15, v3 S)
 {
     v3 v0 = ld3(t15), v1 = ld3(t15 + 3), v2 = ld3(t15 + 6);
@@ -34,7 +48,7 @@ MIRT_HD OriginRow make_origin_row(const float *t15, v3 S)
     float e1e2b = e1e2.x * b.x + e1e2.y * b.y + e1e2.z * b.z;
     OriginRow r;
     r.r0 = make_float4(e1e2.x, e1e2.y, e1e2.z, e1e2b);
-    r.r1 = make_float4(be2.x, be2.y, be2.z, 0.0f);
+    r.r1 = make_float4(be2.x, be2.y, be2.z, origin_near(v0, v1, v2, S));
     r.r2 = make_float4(e1b.x, e1b.y, e1b.z, 0.0f);
     return r;
 }
@@ -205,6 +219,31 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 // 1/0 = +inf, exactly as in the reference; the value is never used again.)
 __device__ __forceinline__ float aa_start(int c, int rs) { return rs > 1 ? (float)c - 0.5f : (float)c; }
 __device__ __forceinline__ float aa_step(int rs) { return 1.0f / (float)(rs - 1); }
+
+// 64-lane min / max without LDS traffic: four row_shr steps fold each row of 16 lanes into its lane 15, row_bcast:15
+// and row_bcast:31 carry the row results into lane 63, v_readlane makes the result wave-uniform (an SGPR).  Lanes a
+// step has no source for are skipped by the hardware and keep their value.  Written as v_min_f32_dpp / v_max_f32_dpp
+// directly (the compiler keeps a separate v_mov_b32_dpp per step otherwise); the s_nop 1 are the two wait states a
+// DPP read needs after a VALU write of the same register.
+#define MIRT_DPP_REDUCE(OP)                                                                      \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"             \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"             \
+        "s_nop 1" : "+v"(v))
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    MIRT_DPP_REDUCE("v_min_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    MIRT_DPP_REDUCE("v_max_f32_dpp");
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef MIRT_DPP_REDUCE
 
 // ---- wavefront min-t primitive ------------------------------------------------------------------------
 // The reference's sequential closest-hit update, `if (closest.distance >= distance)` in index order

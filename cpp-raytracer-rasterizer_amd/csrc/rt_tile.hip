@@ -28,31 +28,6 @@ struct RtTileFrame {
 };
 
 
-// 64-lane min / max without LDS traffic: four row_shr steps fold each row of 16 lanes into its lane 15, row_bcast:15
-// and row_bcast:31 carry the row results into lane 63, v_readlane makes the result wave-uniform (an SGPR).  Lanes a
-// step has no source for are skipped by the hardware and keep their value.  Written as v_min_f32_dpp / v_max_f32_dpp
-// directly (the compiler keeps a separate v_mov_b32_dpp per step otherwise); the s_nop 1 are the two wait states a
-// DPP read needs after a VALU write of the same register.
-#define MIRT_DPP_REDUCE(OP)                                                                      \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                \
-        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                \
-        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                \
-        "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                \
-        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"             \
-        "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"             \
-        "s_nop 1" : "+v"(v))
-__device__ __forceinline__ float wave_min_f(float v)
-{
-    MIRT_DPP_REDUCE("v_min_f32_dpp");
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    MIRT_DPP_REDUCE("v_max_f32_dpp");
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-#undef MIRT_DPP_REDUCE
-
 // interval of g . x for x in the box [lo, hi]
 __device__ __forceinline__ void dot_range(float gx, float gy, float gz, v3 lo, v3 hi, float *rlo, float *rhi)
 {

@@ -147,9 +147,10 @@ struct RtTraceFrame {
     const TriRow *light_rows;         // expanded candidates ordered by light-cube bin (k_expand_light_rows)
     int tiles_x;                      // camera bins per row
     int cube_bins;                    // B: light-cube bins per face side
+    int cam_shells;                   // depth shells per camera bin: bin b's list is cam_off[b * cam_shells] .. cam_off[(b + 1) * cam_shells]
 };
 
-template <bool AA>
+template <bool AA, bool FLAT>
 __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
     const int rs = AA ? f.aa : 1;                          // realSamples (:549-554); compile-time 1 without supersampling
 
     const uint32_t cbin = (uint32_t)ty * (uint32_t)tf.tiles_x + (uint32_t)tx;
-    const uint32_t cbeg = tf.cam_off[cbin], cend = tf.cam_off[cbin + 1];
+    const uint32_t cbeg = tf.cam_off[(size_t)cbin * tf.cam_shells], cend = tf.cam_off[(size_t)(cbin + 1) * tf.cam_shells];
     const float4 *geo4 = reinterpret_cast<const float4 *>(tf.geo);
     const float4 *lrow4 = reinterpret_cast<const float4 *>(tf.light_rows);
 
@@ -186,25 +187,39 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
             const v3 nd = neg3(mat3_mul_vec(f.rot, d));
 
             // ---- primary ray: closest hit of THIS sub-ray among the tile's candidates ----
+            // A candidate whose `near` bound (origin row r1.w: no hit point on it is closer to the camera) lies beyond the
+            // sub-ray's current record cannot replace it, and the record already makes ClosestIntersection return true: the
+            // lane does not queue it; once it lies beyond the record of EVERY pixel of the tile the wave does not even run
+            // the filter.  The lists come roughly front to back (depth shells in the sort key), so after the first drains
+            // most of a list is skipped.  The records are only updated by drains, i.e. the bounds lag -- never the result.
             s.best[lane] = MIN_T_NONE;
             s.flag[lane] = 0u;
-            if (ok) ntests += cend - cbeg;
+            float lane_best = FLT_MAX;                     // distance of the sub-ray's record so far
+            float tile_best = FLT_MAX;                     // max of lane_best over the tile's pixels (wave-uniform)
             for (uint32_t base = cbeg; base < cend; base += TR_STAGE) {
                 const int cnt = (int)min((uint32_t)TR_STAGE, cend - base);
                 wave_lds_fence();                          // the previous chunk's row reads are done
+                float my_near = 0.0f;
                 if (lane < cnt) {
                     const uint32_t idx = tf.cam_entries[base + lane];
                     const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
+                    const float4 a1 = src[1];
                     s.idx[lane] = idx;
                     s.rows[3 * lane] = src[0];
-                    s.rows[3 * lane + 1] = src[1];
+                    s.rows[3 * lane + 1] = a1;
                     s.rows[3 * lane + 2] = src[2];
+                    my_near = a1.w;
                 }
                 wave_lds_fence();
-                for (int j = 0; j < cnt; j++) {
+                unsigned long long pm = __ballot(lane < cnt && !(my_near > tile_best));
+                while (pm) {
+                    const int j = __builtin_ctzll(pm);
+                    pm &= pm - 1ull;
                     const float4 r0 = s.rows[3 * j], r1 = s.rows[3 * j + 1], r2 = s.rows[3 * j + 2];
                     const TestDots td = test_dots(r0, r1, r2, nd);
-                    const bool pass = ok && maybe_hit(td);
+                    const bool live = ok && !(r1.w > lane_best);
+                    if (live) ntests++;
+                    const bool pass = live && maybe_hit(td);
                     const unsigned long long m = __ballot(pass);
                     if (m) {
                         const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -213,7 +228,12 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                             s.qa[at] = make_uint2((uint32_t)lane, s.idx[j]);
                         }
                         qn += __popcll(m);
-                        if (qn >= 64) tr_drain_full<false>(s, lane, qn, geo4, 3, cam);
+                        if (qn >= 64) {
+                            tr_drain_full<false>(s, lane, qn, geo4, 3, cam);
+                            lane_best = min_t_dist(s.best[lane]);
+                            tile_best = wave_max_f(ok ? lane_best : -FLT_MAX);
+                            pm &= __ballot(!(my_near > tile_best));
+                        }
                     }
                 }
             }
@@ -240,9 +260,64 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                     v3 rd;
                     float r;
                     v3 D = light_term(f, k, pos, nDir, &rd, &r);
+                    if (FLAT) {
                     // ---- shadow ray from the light along -rDir (:310): any accepted hit closer than 0.99 r occludes ----
+                    // The rays of a tile fall into ~8 different light-cube bins with lists of very different lengths, so a
+                    // lane walking its own list would leave most of the wave idle (round 1 and the first version of this
+                    // kernel: steps = the LONGEST list).  Instead the (ray, candidate) pairs of the whole wave are numbered
+                    // consecutively -- an exclusive scan of the list lengths -- and lane t of each round takes pair t: a
+                    // six-step search in the scanned starts finds its ray, whose direction and list base sit in LDS.
                     wave_lds_fence();
                     s.thr[lane] = r * 0.99f;                       // (:313)
+                    s.flag[lane] = 0u;
+                    uint32_t lbeg = 0, llen = 0;
+                    if (hit) {
+                        const uint32_t bin = cube_bin_of(rd, (uint32_t)k * 6u * (uint32_t)(tf.cube_bins * tf.cube_bins), tf.cube_bins);
+                        lbeg = tf.light_off[bin]; llen = tf.light_off[bin + 1] - lbeg;
+                    }
+                    uint32_t incl = llen;
+#pragma unroll
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        const uint32_t o = __shfl_up(incl, dd);
+                        if (lane >= dd) incl += o;
+                    }
+                    const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    s.idx[lane] = incl - llen;                     // first pair of this lane's ray
+                    s.pos[lane] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(lbeg));
+                    ntests += llen;
+                    wave_lds_fence();
+                    for (uint32_t t0 = 0; t0 < npairs; t0 += 64) {
+                        const uint32_t t = t0 + (uint32_t)lane;
+                        const bool valid = t < npairs;
+                        int ray = 0;                               // the largest ray whose first pair is <= t
+                        uint32_t first = 0;
+#pragma unroll
+                        for (int step = 32; step >= 1; step >>= 1) {
+                            const uint32_t st = s.idx[ray + step];
+                            if (st <= t) { ray += step; first = st; }
+                        }
+                        const float4 rr = s.pos[ray];
+                        const uint32_t e = __float_as_uint(rr.w) + (t - first);
+                        float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0;
+                        if (valid) { const float4 *src = lrow4 + (size_t)e * 6; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
+                        const TestDots td = test_dots(c0, c1, c2, V3(rr.x, rr.y, rr.z));    // negD = rDir (:310, :229)
+                        const bool pass = valid && maybe_hit(td);
+                        const unsigned long long m = __ballot(pass);
+                        if (m) {
+                            const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (pass) {
+                                s.q[at] = make_float4(td.den, td.pu, td.qv, c0.w);
+                                s.qa[at] = make_uint2((uint32_t)ray, e);
+                            }
+                            qn += __popcll(m);
+                            if (qn >= 64) tr_drain_full<true>(s, lane, qn, lrow4 + 3, 6, L);
+                        }
+                    }
+                    if (qn) { tr_drain<true>(s, lane, qn, lrow4 + 3, 6, L); qn = 0; }
+                    } else {
+                    wave_lds_fence();
+                    const float thr = r * 0.99f;                   // (:313)
+                    s.thr[lane] = thr;
                     s.flag[lane] = 0u;
                     uint32_t e = 0, end = 0;
                     if (hit) {
@@ -258,7 +333,8 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                         float4 n0 = c0, n1 = c1, n2 = c2;
                         if (nact) { const float4 *src = lrow4 + (size_t)(e + 1) * 6; n0 = src[0]; n1 = src[1]; n2 = src[2]; }
                         const TestDots td = test_dots(c0, c1, c2, rd);           // negD = rDir (:310, :229)
-                        const bool pass = act && maybe_hit(td);
+                        // a candidate none of whose points is closer to the light than 0.99 r cannot occlude (:313)
+                        const bool pass = act && !(c1.w > thr) && maybe_hit(td);
                         if (act) ntests++;
                         const unsigned long long m = __ballot(pass);
                         bool occ = false;
@@ -279,6 +355,7 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                         act = nact && !occ;
                     }
                     if (qn) { tr_drain<true>(s, lane, qn, lrow4 + 3, 6, L); qn = 0; }
+                    }
                     if (s.flag[lane] != 0u) D = V3(0.0f, 0.0f, 0.0f);           // occluded (:313-314); any-hit is exact
                     result = add3(result, D);                      // (:319)
                     if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
@@ -306,8 +383,10 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
 
-template __global__ void k_rt_trace<false>(const RtTraceFrame);
-template __global__ void k_rt_trace<true>(const RtTraceFrame);
+template __global__ void k_rt_trace<false, false>(const RtTraceFrame);
+template __global__ void k_rt_trace<true, false>(const RtTraceFrame);
+template __global__ void k_rt_trace<false, true>(const RtTraceFrame);
+template __global__ void k_rt_trace<true, true>(const RtTraceFrame);
 
 size_t rt_trace_lds_bytes() { return 4 * sizeof(TrWaveLds); }
 

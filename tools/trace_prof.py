@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""tools/trace_prof.py [nolight] -- a dozen binned frames of the 100 k soup at 1080p (static camera), for rocprofv3:
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES ... -d gpurun_out/x -- python3 tools/trace_prof.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), os.path.join(ROOT, "tests")]
+import mirt                                 # noqa: E402
+from devbuf import DeviceArray              # noqa: E402
+
+W, H = 1920, 1080
+lights = np.zeros((0, 7), np.float32) if "nolight" in sys.argv else np.array([[0.0, -0.5, -0.7, 1, 1, 1, 14]], np.float32)
+mirt.init(0)
+mirt.scene_upload(mirt.scene_soup(1, 100000, 0.05))
+view = mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.0, 1.0), 540.0, W, H)
+x = DeviceArray((H, W), np.uint32)
+for it in range(12):
+    mirt.raytrace_device(view, lights, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, x.ptr, W * 4)
+mirt.sync()
+print(mirt.stats())
+mirt.shutdown()
