@@ -135,7 +135,8 @@ struct Ctx {
     // scene
     int n = 0;
     float *d_tris = nullptr;
-    uint8_t *d_culled = nullptr;
+    uint8_t *d_culled = nullptr;                 // isCulled flags: [0, n) for frames on streams[0], [n, 2n) for streams[1] (frames in flight)
+    int culled_latest = 0;                       // which half the most recent cull call wrote (mirt_scene_get_culled reads it)
     RtScratch rt[2];                             // per-stream tables of the non-tile ray-trace paths (frames in flight)
     GeoRow *d_geo = nullptr;                     // n geometry rows (built by mirt_scene_upload)
     float bbox_lo[3] = { 0, 0, 0 }, bbox_hi[3] = { 0, 0, 0 };   // the scene's bounding box (host side, mirt_scene_upload)
@@ -147,7 +148,8 @@ struct Ctx {
     float4 *d_tile_tab[2] = { nullptr, nullptr };   // per-stream tables of the tile ray tracer (k_tile_tables)
     int hits_tog[2] = { 0, 0 };
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
-    uint64_t scene_version = 0;                  // bumped whenever triangles or cull flags change
+    uint64_t scene_version = 0;                  // bumped whenever the triangles change
+    uint64_t cull_version = 0;                   // bumped whenever the cull flags change (rasteriser sizing only)
     int soft_samples = 1;                        // soft-shadow samples per light (1 = hard shadows)
     int aa = 1;                                  // realSamples of Draw(): AA_SAMPLES when AA_ENABLED, else 1
     int dof_k = 0;                               // DOF_KERNEL_SIZE when DOF_ENABLED, else 0
@@ -170,6 +172,7 @@ struct Ctx {
     // statistics of the last call
     mirt_stats stats = {};
     bool stats_pending = false;
+    bool raster_since_sync = false;              // rasteriser frames were queued since the last mirt_sync (overflow check there)
     bool call_timed = false;                     // the last call recorded its start / end events (profiling was on)
     hipStream_t stats_stream = nullptr;          // the stream the last call ran on
     uint64_t pending_primary = 0;
@@ -999,6 +1002,21 @@ extern "C" int mirt_sync(void)
     int rc;
     if ((rc = need_init())) return rc;
     HIP_TRY(sync_all());
+    // A rasteriser frame whose row tables were sized from a cached count reports a table that turned out too small in
+    // counters[1] (it would have dropped the rows of the triangles that did not fit): surface it here, where the caller
+    // waits for its frames, instead of presenting such a frame silently.
+    if (g.raster_since_sync) {
+        g.raster_since_sync = false;
+        for (RasterScratch &R : g.raster)
+            if (R.counters) {
+                uint32_t c[2] = { 0, 0 };
+                HIP_TRY(hipMemcpy(c, R.counters, sizeof c, hipMemcpyDeviceToHost));
+                if (c[1]) {
+                    R.sizing_valid = false;
+                    return fail(MIRT_ERR_HIP, "rasteriser: the row tables (%zu rows) were too small for a frame; its sizing cache is dropped, render the frame again", R.cap_rows);
+                }
+            }
+    }
     return MIRT_OK;
 }
 
@@ -1010,6 +1028,10 @@ extern "C" int mirt_set_frames_in_flight(int frames)
     if ((rc = need_init())) return rc;
     if (frames < 1 || frames > 2) return fail(MIRT_ERR_INVALID_ARGUMENT, "frames in flight must be 1 or 2, not %d", frames);
     HIP_TRY(sync_all());
+    if (g.d_culled && g.n > 0) {                 // both halves of the cull flags start from the most recent ones
+        const size_t from = (size_t)g.culled_latest * g.n, to = (size_t)(g.culled_latest ^ 1) * g.n;
+        HIP_TRY(hipMemcpy(g.d_culled + to, g.d_culled + from, (size_t)g.n, hipMemcpyDeviceToDevice));
+    }
     g.in_flight = frames;
     g.stream = g.streams[0];
     g.last_stream = 1;                       // the first overlapping frame takes streams[0]
@@ -1027,11 +1049,13 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     HIP_TRY(sync_all());
     g.n = 0;
     if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
-    if ((rc = dev_realloc(&g.d_culled, (size_t)n))) return rc;
+    if ((rc = dev_realloc(&g.d_culled, (size_t)2 * n))) return rc;
     for (RtScratch &S : g.rt) S.bin_key_valid = false;      // the origin tables are re-sized by the next frame that needs them
     HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
-    if (culled) HIP_TRY(hipMemcpy(g.d_culled, culled, (size_t)n, hipMemcpyHostToDevice));
-    else HIP_TRY(hipMemset(g.d_culled, 0, (size_t)n));
+    for (int h = 0; h < 2; h++) {
+        if (culled) HIP_TRY(hipMemcpy(g.d_culled + (size_t)h * n, culled, (size_t)n, hipMemcpyHostToDevice));
+        else HIP_TRY(hipMemset(g.d_culled + (size_t)h * n, 0, (size_t)n));
+    }
     if ((rc = dev_realloc(&g.d_geo, (size_t)n))) return rc;
     hipLaunchKernelGGL(k_geo_table, dim3((n + 255) / 256), dim3(256), 0, g.stream, g.d_tris, n, g.d_geo);
     HIP_TRY(hipGetLastError());
@@ -1058,10 +1082,12 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
     if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
     if (n != g.n) return fail(MIRT_ERR_INVALID_ARGUMENT, "cull array has %d entries, scene has %d triangles", n, g.n);
     HIP_TRY(sync_all());
-    if (culled) HIP_TRY(hipMemcpyAsync(g.d_culled, culled, (size_t)n, hipMemcpyHostToDevice, g.stream));
-    else HIP_TRY(hipMemsetAsync(g.d_culled, 0, (size_t)n, g.stream));
+    for (int h = 0; h < 2; h++) {
+        if (culled) HIP_TRY(hipMemcpyAsync(g.d_culled + (size_t)h * n, culled, (size_t)n, hipMemcpyHostToDevice, g.stream));
+        else HIP_TRY(hipMemsetAsync(g.d_culled + (size_t)h * n, 0, (size_t)n, g.stream));
+    }
     HIP_TRY(hipStreamSynchronize(g.stream));
-    g.scene_version++;
+    g.cull_version++;
     return MIRT_OK;
 }
 
@@ -1075,20 +1101,16 @@ extern "C" int mirt_cull_device(const mirt_view *view, int flags)
     if (view->width <= 0 || view->height <= 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "frame %d x %d", view->width, view->height);
     CullParams cp;
     cull_setup(view, flags, &cp);
-    // A barrier call, ordered on the device (no host sync): frames in flight on either stream read the flags, so the
-    // kernel waits for both streams, and every later frame -- whichever stream it takes -- waits for the kernel.
-    const int other = (g.stream == g.streams[0]) ? 1 : 0;
-    if (g.in_flight == 2) {
-        HIP_TRY(hipEventRecord(g.ev_chain, g.streams[other]));
-        HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_chain, 0));
-    }
-    hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, g.stream, g.d_tris, g.n, cp, g.d_culled);
+    // The flags belong to the NEXT frame (the reference culls in Update(), right before Draw()): with two frames in flight
+    // they go into the half of d_culled that belongs to the stream that frame will take, on that stream, in order in front of
+    // it -- the frame still running on the other stream keeps its own flags, nothing waits for anything.
+    const int half = (g.in_flight == 2) ? (g.last_stream ^ 1) : 0;
+    hipStream_t st = (g.in_flight == 2) ? g.streams[half] : g.stream;
+    (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (see call_begin)
+    hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.d_tris, g.n, cp, g.d_culled + (size_t)half * g.n);
     HIP_TRY(hipGetLastError());
-    if (g.in_flight == 2) {
-        HIP_TRY(hipEventRecord(g.ev_cull, g.stream));
-        HIP_TRY(hipStreamWaitEvent(g.streams[other], g.ev_cull, 0));
-    }
-    g.scene_version++;
+    g.culled_latest = half;
+    g.cull_version++;
     return MIRT_OK;
 }
 
@@ -1099,7 +1121,7 @@ extern "C" int mirt_scene_get_culled(uint8_t *culled, int n)
     if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
     if (!culled || n != g.n) return fail(MIRT_ERR_INVALID_ARGUMENT, "cull array has %d entries, scene has %d triangles", n, g.n);
     HIP_TRY(sync_all());
-    HIP_TRY(hipMemcpy(culled, g.d_culled, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(culled, g.d_culled + (size_t)g.culled_latest * g.n, (size_t)n, hipMemcpyDeviceToHost));
     return MIRT_OK;
 }
 
@@ -1217,7 +1239,7 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     RasterFrame f;
     memset(&f, 0, sizeof f);
     f.tris15 = g.d_tris;
-    f.culled = g.d_culled;
+    f.culled = g.d_culled + ((g.in_flight == 2 && g.stream == g.streams[1]) ? (size_t)g.n : 0);
     f.n = g.n;
     memcpy(f.cam, view->pos, 12);
     memcpy(f.rot, view->rot, 36);
@@ -1240,7 +1262,8 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     f.focal_plane = g.dof_focal;
     if ((rc = raster_scratch_ensure(scratch, g.n, view->width, y1 - y0))) return fail(rc, "raster scratch allocation failed");
     if (g.profiling) for (int k = MIRT_K_RASTER_SETUP; k <= MIRT_K_CLEAR; k++) g.ev_used[k] = true;
-    if ((rc = launch_raster(f, scratch, g.scene_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr)))
+    g.raster_since_sync = true;
+    if ((rc = launch_raster(f, scratch, g.scene_version * 0x9E3779B97F4A7C15ull + g.cull_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr)))
         return fail(rc, "rasteriser launch failed: %s", hipGetErrorString(hipGetLastError()));
     call_end();
     return MIRT_OK;
@@ -1311,6 +1334,8 @@ extern "C" int mirt_get_stats(mirt_stats *out)
                 g.stats.tests = (g.stats.primary_rays + g.stats.shadow_rays) * (uint64_t)g.n;
         }
         g.stats_pending = false;
+        (void)hipGetLastError();                 // an event pair a frame never recorded (no clear needed, ...) leaves hipErrorInvalidHandle
+                                                 // behind: do not hand it to the next HIP user of this thread
     }
     *out = g.stats;
     return MIRT_OK;

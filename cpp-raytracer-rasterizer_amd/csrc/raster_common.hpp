@@ -41,9 +41,11 @@ struct RasterScratch {
     float *slots = nullptr;          // cap_rows * 3 * SLOT_FIELDS
     Span *spans = nullptr;           // cap_rows
     unsigned long long *keys = nullptr;   // band pixels
-    uint32_t *counters = nullptr;    // [0] total rows, [1] overflow flag
+    uint32_t *counters = nullptr;    // [0] total rows, [1] overflow flag, [2] rows of the tallest triangle
+    uint32_t max_rows = 0;           // counters[2] of the last sizing pass
     int cap_tris = 0;
-    size_t cap_rows = 0;
+    size_t cap_rows = 0;             // rows the slot table holds (and the span table, at least)
+    size_t cap_spans = 0;            // rows the span table holds (>= cap_rows; the worst case n x band rows for small scenes)
     size_t cap_px = 0;
     size_t keys_zero_px = 0;         // keys[0 .. keys_zero_px) are known to be zero (k_raster_resolve re-zeroes what a frame used)
     // sizing cache: the total row count of the previous frame with the same inputs

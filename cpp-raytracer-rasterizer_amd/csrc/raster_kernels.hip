@@ -21,6 +21,8 @@
 #include "scan.hpp"
 
 #include <limits.h>
+#include <algorithm>
+#include <cstdlib>
 
 #include "cull.hpp"
 
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(256) void k_raster_vertex(const RasterFrame f)
     const TriSetup s = vertex_setup(f, t);
     f.scratch.setup[t] = s;
     f.scratch.row_base[t] = (uint32_t)s.rows;     // scanned in place by k_scan_*
+    if (s.rows > 0) atomicMax(&f.scratch.counters[2], (uint32_t)s.rows);      // the tallest triangle (zeroed by the host per sizing pass)
 }
 
 // ---- exclusive scan of row counts (3 passes, 1024 items per block) -----------------------------------
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint32_t *__restrict__ data,
 __global__ __launch_bounds__(256) void k_raster_vertex_scan(const RasterFrame f)
 {
     __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+    if (threadIdx.x == 0) { s_carry = 0; f.scratch.counters[2] = 0u; }
     __syncthreads();
     for (int base = 0; base < f.n; base += SCAN_ITEMS) {
         const int i0 = base + threadIdx.x * 4;
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(256) void k_raster_vertex_scan(const RasterFrame f)
                 const TriSetup s = vertex_setup(f, i0 + i);
                 f.scratch.setup[i0 + i] = s;
                 v[i] = (uint32_t)s.rows;
+                if (s.rows > 0) atomicMax(&f.scratch.counters[2], (uint32_t)s.rows);
             }
         }
         uint32_t total;
@@ -161,7 +165,9 @@ __global__ __launch_bounds__(256) void k_raster_vertex_scan(const RasterFrame f)
 }
 
 // ---- left/right per row (rasteriser.cpp:716-733) and the span constants (:646-649) --------------------
-__device__ __forceinline__ void build_span(const RasterFrame &f, const TriSetup &s, int t, uint32_t r, int y)
+// get(edge, field) = field {x, zinv, p.x, p.y, p.z} of that edge's sample on this row (global scratch table or the workgroup's LDS copy)
+template <class Get>
+__device__ __forceinline__ void build_span(const RasterFrame &f, const TriSetup &s, int t, uint32_t r, int y, Get get)
 {
     int lx = INT_MAX, rx = -INT_MAX;
     float lz = 0.0f, rz = 0.0f;
@@ -170,10 +176,11 @@ __device__ __forceinline__ void build_span(const RasterFrame &f, const TriSetup 
     for (int e = 0; e < 3; e++) {
         const int ya = s.y[e], yb = s.y[(e + 1) % 3];
         if (y < min(ya, yb) || y > max(ya, yb)) continue;       // this edge has no sample on this row
-        const float *slot = f.scratch.slots + ((size_t)r * 3 + e) * SLOT_FIELDS;
-        const int x = __float_as_int(slot[0]);
-        if (x < lx) { lx = x; lz = slot[1]; lp = V3(slot[2], slot[3], slot[4]); }   // strict <, first edge wins ties
-        if (x > rx) { rx = x; rz = slot[1]; rp = V3(slot[2], slot[3], slot[4]); }   // strict >
+        const int x = __float_as_int(get(e, 0));
+        const float sz = get(e, 1);
+        const v3 sp3 = V3(get(e, 2), get(e, 3), get(e, 4));
+        if (x < lx) { lx = x; lz = sz; lp = sp3; }   // strict <, first edge wins ties
+        if (x > rx) { rx = x; rz = sz; rp = sp3; }   // strict >
     }
     Span sp;
     sp.tri = t; sp.y = y;
@@ -213,13 +220,13 @@ __device__ __forceinline__ EdgeWalk edge_walk(const TriSetup &s, int e)
     return w;
 }
 
-__global__ __launch_bounds__(256) void k_raster_edges(const RasterFrame f)
+__global__ __launch_bounds__(256) void k_raster_edges(const RasterFrame f, int handled_rows)
 {
     __shared__ float bufs[2][EDGE_CHUNK * 15];
     const int t = blockIdx.x;
     const TriSetup &s = f.scratch.setup[t];
     const int rows = s.rows;
-    if (rows == 0) return;
+    if (rows == 0 || rows <= handled_rows) return;      // (k_raster_edges_lds took the triangles of up to handled_rows rows)
     const size_t base = f.scratch.row_base[t];
     if (base + (size_t)rows > f.scratch.cap_rows) { if (threadIdx.x == 0) atomicExch(&f.scratch.counters[1], 1u); return; }
 
@@ -283,7 +290,83 @@ __global__ __launch_bounds__(256) void k_raster_edges(const RasterFrame f)
     }
     // all edge samples of this triangle are in its slots (written by this workgroup, barrier above): build the spans
     __threadfence_block();
-    for (int r = threadIdx.x; r < rows; r += 256) build_span(f, s, t, (uint32_t)(base + r), s.r0 + r);
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float *slot = f.scratch.slots + (base + r) * 3 * SLOT_FIELDS;
+        build_span(f, s, t, (uint32_t)(base + r), s.r0 + r, [&](int e, int fld) { return slot[e * SLOT_FIELDS + fld]; });
+    }
+}
+
+// ---- the same with the sample table in LDS ---------------------------------------------------------------------------------
+// k_raster_edges stages the samples through LDS into a global slot table in chunks of 512 steps (barrier per chunk, 120
+// flush lanes, then the span pass reads the table back): 48 us for the 20 visible triangles of the Cornell box at 4K, a
+// third of the frame, on 20 CUs.  A triangle of R rows needs at most R x 15 samples -- 130 KB at R = 2160, which a CU's
+// 160 KB of LDS holds.  So triangles of up to `lds_rows` rows keep all their samples in LDS and the spans are built from
+// there; taller ones take k_raster_edges.
+//
+// What bounds the kernel is the dependent float chain, walked by ONE wave that is alone on its SIMD.  Measured
+// (tools/edgebench.hip): such a wave issues an instruction every ~8.6 cycles, dependent or not, and every LDS store in the
+// stream costs about two more slots, whatever its width.  So the chain loop is stripped to what must be sequential:
+//   * all 15 chains (3 edges x {x, zinv, pos3d.xyz}) sit in lanes 0..14 of wave 0 and run the SAME number of steps (the
+//     longest edge; a shorter edge computes samples nobody reads), so the loop is wave-uniform: scalar loop control, no
+//     exec-mask bookkeeping, unrolled 32 steps deep;
+//   * the table is indexed by STEP, not by row (sample k of channel c at s[c*stride + k]): every lane stores to the same
+//     offset, four consecutive steps are 16 contiguous bytes = one ds_write_b128 per four v_add_f32; the span pass maps a
+//     row to each edge's step (k = (y - ystart) * dir);
+//   * the x chains store the float; `result[i].x = current.x` (:628, truncation) is applied by the span pass.
+// ~1.3 instructions per step instead of ~4.  The workgroup has 1024 threads: the span pass that follows the barrier (four
+// IEEE divides and a 48-byte store per row) is spread over 16 waves instead of 4 lone ones.
+__device__ __forceinline__ int edge_lds_stride(int lds_rows) { return ((lds_rows + 3) & ~3) + 4; }
+
+__global__ __launch_bounds__(1024) void k_raster_edges_lds(const RasterFrame f, int lds_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_steps[];      // 15 channels x stride
+    const int t = blockIdx.x;
+    const TriSetup &s = f.scratch.setup[t];
+    const int rows = s.rows;
+    if (rows == 0 || rows > lds_rows) return;
+    const size_t base = f.scratch.row_base[t];
+    if (base + (size_t)rows > f.scratch.cap_rows) { if (threadIdx.x == 0) atomicExch(&f.scratch.counters[1], 1u); return; }
+    const int stride = edge_lds_stride(lds_rows);
+    const EdgeWalk w0 = edge_walk(s, 0), w1 = edge_walk(s, 1), w2 = edge_walk(s, 2);
+
+    const int tid = threadIdx.x;
+    if (tid < 64) {                                  // wave 0: lane = channel = edge*5 + field
+        const int e = min(tid / SLOT_FIELDS, 2), fld = tid - e * SLOT_FIELDS;
+        const int i = e, j = (e + 1) % 3;
+        const int N = abs(s.y[i] - s.y[j]) + 1;                      // :713
+        const float div = (float)max(N - 1, 1);                      // :622
+        float cur, step;
+        if (fld == 0) { cur = (float)s.x[i]; step = (float)(s.x[j] - s.x[i]) / div; }
+        else if (fld == 1) { cur = s.zinv[i]; step = (s.zinv[j] - s.zinv[i]) / div; }
+        else { cur = s.p[i][min(fld - 2, 2)]; step = (s.p[j][min(fld - 2, 2)] - s.p[i][min(fld - 2, 2)]) / div; }
+        const EdgeWalk w = (e == 0) ? w0 : (e == 1) ? w1 : w2;
+        // samples before the band are walked, not stored: `skip` pure additions (wave-uniform count: the longest)
+        const int skipmax = max(max(w0.skip, w1.skip), w2.skip);
+        for (int k = 0; k < skipmax; k++) cur = (k < w.skip) ? cur + step : cur;      // :632-635, sequential on purpose
+        const int groups = (max(max(w0.cnt, w1.cnt), w2.cnt) + 3) >> 2;          // wave-uniform
+        float4 *dst = reinterpret_cast<float4 *>(s_steps + min(tid, 14) * stride);
+        if (tid < 15) {
+#pragma unroll 8
+            for (int g4 = 0; g4 < groups; g4++) {
+                float4 v;
+                v.x = cur; cur += step;
+                v.y = cur; cur += step;
+                v.z = cur; cur += step;
+                v.w = cur; cur += step;
+                dst[g4] = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int dirs[3] = { w0.dir, w1.dir, w2.dir }, starts[3] = { w0.ystart, w1.ystart, w2.ystart };
+    for (int r = tid; r < rows; r += (int)blockDim.x) {
+        const int y = s.r0 + r;
+        build_span(f, s, t, (uint32_t)(base + r), y, [&](int e2, int f2) {
+            const int k = (y - starts[e2]) * dirs[e2];               // this row's sample of edge e2
+            const float v = s_steps[(e2 * SLOT_FIELDS + f2) * stride + k];
+            return f2 == 0 ? __int_as_float((int)v) : v;             // :628 (|x| < 2^21 in contract: (int) equals the x86 conversion)
+        });
+    }
 }
 
 // ---- fragments with an atomic z-compare (rasteriser.cpp:603-610, 657-669) -----------------------------
@@ -382,7 +465,10 @@ static int ensure_rows(RasterScratch &s, size_t rows)
     if (rows <= s.cap_rows) return MIRT_OK;
     size_t cap = rows + rows / 8 + 1024;
     if (grow((void **)&s.slots, cap * 3 * SLOT_FIELDS * sizeof(float))) { s.cap_rows = 0; return MIRT_ERR_OUT_OF_MEMORY; }
-    if (grow((void **)&s.spans, cap * sizeof(Span))) { s.cap_rows = 0; return MIRT_ERR_OUT_OF_MEMORY; }
+    if (s.cap_spans < cap) {
+        if (grow((void **)&s.spans, cap * sizeof(Span))) { s.cap_rows = 0; s.cap_spans = 0; return MIRT_ERR_OUT_OF_MEMORY; }
+        s.cap_spans = cap;
+    }
     s.cap_rows = cap;
     return MIRT_OK;
 }
@@ -439,28 +525,63 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     if (f.n <= 4096) {
         hipLaunchKernelGGL(k_raster_vertex_scan, dim3(1), dim3(256), 0, stream, f);
     } else {
+        if (hipMemsetAsync(s.counters + 2, 0, 4, stream) != hipSuccess) return MIRT_ERR_HIP;      // tallest triangle (atomicMax below)
         hipLaunchKernelGGL(k_raster_vertex, dim3((f.n + 255) / 256), dim3(256), 0, stream, f);
         enqueue_exclusive_scan(s.row_base, f.n, s.block_sums, s.counters, stream);
     }
 
-    // The slot / span tables are sized from the total row count.  It is read back (one 4-byte copy + sync)
-    // only when the frame's geometry inputs changed since the last call; otherwise last frame's count holds.
-    const uint64_t key = frame_key(f, scene_version);
-    if (!s.sizing_valid || s.sizing_key != key) {
-        uint32_t total = 0;
-        if (hipMemcpyAsync(&total, s.counters, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MIRT_ERR_HIP;
-        if (hipStreamSynchronize(stream) != hipSuccess) return MIRT_ERR_HIP;
-        if (ensure_rows(s, total)) return MIRT_ERR_OUT_OF_MEMORY;
-        s.sizing_key = key;
-        s.sizing_valid = true;
+    // The span table (and the slot table of k_raster_edges) is sized from the total row count, which only the device knows.
+    //  * Small scenes -- n x band rows spans fit 64 MiB, e.g. the Cornell box at any size -- get the worst case once and
+    //    never ask: no read-back, no sync, whatever the camera does.
+    //  * Otherwise the count is read back (16 bytes + one sync of this stream) when the frame's geometry inputs changed since
+    //    the last call; a frame with the same inputs reuses the count.
+    static const int lds_rows_max = [] { const char *e = getenv("MIRT_RASTER_LDS_ROWS"); int v = e ? atoi(e) : 2560; return v < 0 ? 0 : (v > 2560 ? 2560 : v); }();
+    const size_t worst_rows = (size_t)f.n * (size_t)band_rows;
+    const bool worst_case = f.n <= 4096 && worst_rows * sizeof(Span) <= ((size_t)64 << 20) && lds_rows_max > 0;
+    int lds_rows;
+    bool tall;                                           // some triangle may be taller than the LDS kernel takes
+    if (worst_case) {
+        if (s.cap_spans < worst_rows) {
+            if (grow((void **)&s.spans, worst_rows * sizeof(Span))) { s.cap_spans = 0; return MIRT_ERR_OUT_OF_MEMORY; }
+            s.cap_spans = worst_rows;
+        }
+        lds_rows = std::min(band_rows, lds_rows_max);
+        tall = band_rows > lds_rows;
+        if (tall && ensure_rows(s, worst_rows)) return MIRT_ERR_OUT_OF_MEMORY;      // slot table of the chunked kernel
         f.scratch = s;
+        f.scratch.cap_rows = s.cap_spans;
+    } else {
+        const uint64_t key = frame_key(f, scene_version);
+        if (!s.sizing_valid || s.sizing_key != key) {
+            uint32_t c[4] = { 0, 0, 0, 0 };               // [0] total rows, [1] overflow flag, [2] tallest triangle
+            if (hipMemcpyAsync(c, s.counters, sizeof c, hipMemcpyDeviceToHost, stream) != hipSuccess) return MIRT_ERR_HIP;
+            if (hipStreamSynchronize(stream) != hipSuccess) return MIRT_ERR_HIP;
+            if (ensure_rows(s, c[0])) return MIRT_ERR_OUT_OF_MEMORY;
+            s.max_rows = c[2];
+            s.sizing_key = key;
+            s.sizing_valid = true;
+        }
+        f.scratch = s;
+        lds_rows = (int)std::min<uint32_t>(s.max_rows, (uint32_t)lds_rows_max);
+        tall = s.max_rows > (uint32_t)lds_rows;
     }
-    // edge walk + span build, one workgroup per triangle
-    hipLaunchKernelGGL(k_raster_edges, dim3(f.n), dim3(256), 0, stream, f);
+    // edge walk + span build, one workgroup per triangle: samples in LDS for triangles of up to lds_rows rows (60 bytes per
+    // row, at most 150 KiB), the chunked global-table kernel for taller ones
+    if (lds_rows > 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raster_edges_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 4 * (2560 + 4));
+            attr_set = true;
+        }
+        // 1024 threads where the span pass has rows to spread them over; small triangles keep 256 (more workgroups per CU)
+        const int threads = lds_rows > 512 ? 1024 : 256;
+        hipLaunchKernelGGL(k_raster_edges_lds, dim3(f.n), dim3(threads), (size_t)15 * 4 * (((lds_rows + 3) & ~3) + 4), stream, f, lds_rows);
+    }
+    if (tall) hipLaunchKernelGGL(k_raster_edges, dim3(f.n), dim3(256), 0, stream, f, lds_rows);
     end(MIRT_K_RASTER_SETUP);
 
     begin(MIRT_K_RASTER_FRAG);
-    const int frag_blocks = (int)min((size_t)8192, (s.cap_rows + 3) / 4);
+    const int frag_blocks = (int)min((size_t)8192, (f.scratch.cap_rows + 3) / 4);
     hipLaunchKernelGGL(k_raster_frag, dim3(frag_blocks), dim3(256), 0, stream, f);
     end(MIRT_K_RASTER_FRAG);
 

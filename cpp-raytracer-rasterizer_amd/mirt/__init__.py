@@ -259,12 +259,12 @@ def raytrace(view, lights7, indirect=(0.2, 0.2, 0.2), mode=RT_AUTO, want_rgb=Tru
     return out
 
 
-def rasterise(view, lights7, indirect=(0.2, 0.2, 0.2), want_rgb=True, want_zinv=True, want_index=True):
+def rasterise(view, lights7, indirect=(0.2, 0.2, 0.2), want_rgb=True, want_zinv=True, want_index=True, xrgb=None):
     W, H = view.width, view.height
     larr, nl = make_lights(lights7)
     ind = np.asarray(indirect, np.float32)
     out = {
-        "xrgb": np.full((H, W), 0xDEADBEEF, np.uint32),
+        "xrgb": np.full((H, W), 0xDEADBEEF, np.uint32) if xrgb is None else xrgb,
         "rgb": np.zeros((H, W, 3), np.float32) if want_rgb else None,
         "depth": np.zeros((H, W), np.float32) if want_zinv else None,
         "index": np.zeros((H, W), np.int32) if want_index else None,
@@ -326,6 +326,19 @@ def prepared_rasterise_device(view, lights7, indirect, y0, y1, row_origin, d_xrg
 
     def launch(_keep=(view, larr, ind)):
         rc = fn(*args)
+        if rc:
+            _check(rc)
+    return launch
+
+
+def prepared_cull_device(view, flags=3):
+    """Zero-argument callable that runs the cull step for `view` on the device (see prepared_raytrace_device)."""
+    lib = load()
+    ref = C.byref(view)
+    fn = lib.mirt_cull_device
+
+    def launch(_keep=(view,)):
+        rc = fn(ref, int(flags))
         if rc:
             _check(rc)
     return launch
