@@ -164,6 +164,9 @@ struct Ctx {
     int soft_npos = 0;
     float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
 
+    // host surfaces the caller registered (mirt_surface_register): pinned + mapped, so the frame reaches them at link speed
+    struct HostSurface { char *host = nullptr; char *dev = nullptr; size_t bytes = 0; } surf[4];
+
     // staging for the host-buffer entry points
     void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr, *d_pos = nullptr;
     size_t cap_px = 0;
@@ -847,6 +850,27 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     return MIRT_OK;
 }
 
+// The device alias of a host pointer inside a registered surface (rows [0, H) of `pitch` bytes must fit), or NULL.
+char *registered_alias(const void *host, size_t pitch, int H)
+{
+    const char *p = static_cast<const char *>(host);
+    for (const Ctx::HostSurface &r : g.surf)
+        if (r.host && p >= r.host && p + pitch * (size_t)H <= r.host + r.bytes) return r.dev + (p - r.host);
+    return nullptr;
+}
+
+// How a frame reaches a REGISTERED host surface: 0 (default) = device staging plane + one DMA copy into the pinned surface,
+// 1 = the render kernels store their XRGB words straight into the mapped surface (no staging plane, no copy; the stores cross
+// the link while the frame is still being computed).  MIRT_HOST_PATH=direct|dma.  Measured on the MI355X box (bench.py
+// host_path): 1080p ray tracer 0.226 (dma) / 0.230 (direct) / 0.224 ms (unregistered, pageable) per frame, 4K rasteriser
+// 0.71 (pageable) / 0.90 ms (direct) -- the runtime's own staging of pageable copies already runs at the rate the link gives
+// here (37-46 GB/s), so registering buys nothing on this machine and direct stores lose to the DMA engine on large frames.
+bool host_direct()
+{
+    static const bool direct = [] { const char *e = getenv("MIRT_HOST_PATH"); return e && !strcmp(e, "direct"); }();
+    return direct;
+}
+
 int copy_plane_interior(void *dst, int dst_pitch, const void *src, int src_pitch, int W, int H)
 {
     // rows 1..H-2, columns 1..W-2 only: the reference never writes the 1-pixel border (raytracer.cpp:618-620)
@@ -980,6 +1004,7 @@ extern "C" void mirt_shutdown(void)
                      (void *)g.dof[0].rgb, (void *)g.dof[0].fd, (void *)g.dof[0].xrgb, (void *)g.dof[0].index, (void *)g.dof[0].zinv,
                      (void *)g.dof[1].rgb, (void *)g.dof[1].fd, (void *)g.dof[1].xrgb, (void *)g.dof[1].index, (void *)g.dof[1].zinv })
         if (p) (void)hipFree(p);
+    for (Ctx::HostSurface &r : g.surf) if (r.host) (void)hipHostUnregister(r.host);
     raster_scratch_free(g.raster[0]);
     raster_scratch_free(g.raster[1]);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
@@ -1037,6 +1062,41 @@ extern "C" int mirt_set_frames_in_flight(int frames)
     g.last_stream = 1;                       // the first overlapping frame takes streams[0]
     g.last_self_contained = false;
     return MIRT_OK;
+}
+
+// ---- host surfaces ------------------------------------------------------------------------------------
+
+extern "C" int mirt_surface_register(void *pixels, size_t bytes)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!pixels || bytes == 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "surface must not be NULL / empty");
+    for (Ctx::HostSurface &r : g.surf)
+        if (r.host == pixels && r.bytes == bytes) return MIRT_OK;
+    Ctx::HostSurface *slot = nullptr;
+    for (Ctx::HostSurface &r : g.surf) if (!r.host) { slot = &r; break; }
+    if (!slot) return fail(MIRT_ERR_INVALID_ARGUMENT, "at most %d surfaces can be registered at a time", (int)(sizeof g.surf / sizeof g.surf[0]));
+    hipError_t e = hipHostRegister(pixels, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRT_ERR_HIP, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    void *dev = nullptr;
+    e = hipHostGetDevicePointer(&dev, pixels, 0);
+    if (e != hipSuccess || !dev) { (void)hipHostUnregister(pixels); (void)hipGetLastError(); return fail(MIRT_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    slot->host = static_cast<char *>(pixels); slot->dev = static_cast<char *>(dev); slot->bytes = bytes;
+    return MIRT_OK;
+}
+
+extern "C" int mirt_surface_unregister(void *pixels)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    for (Ctx::HostSurface &r : g.surf)
+        if (r.host && r.host == pixels) {
+            HIP_TRY(sync_all());
+            (void)hipHostUnregister(r.host);
+            r = Ctx::HostSurface();
+            return MIRT_OK;
+        }
+    return fail(MIRT_ERR_INVALID_ARGUMENT, "surface %p is not registered", pixels);
 }
 
 // ---- scene ------------------------------------------------------------------------------------------
@@ -1203,10 +1263,12 @@ extern "C" int mirt_raytrace_ex(const mirt_view *view, const mirt_light *lights,
     const size_t px = (size_t)W * H;
     // closestIntersections[].distance shares the depth staging plane of the rasteriser entry point; .position gets its own
     if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, out_distance != nullptr, out_position != nullptr))) return rc;
-    if ((rc = mirt_raytrace_device_ex(view, lights, nlights, indirect, mode, 0, H, 0, g.d_xrgb, W * 4,
+    char *alias = registered_alias(out_xrgb, (size_t)pitch_bytes, H);
+    const bool direct = alias && host_direct();
+    if ((rc = mirt_raytrace_device_ex(view, lights, nlights, indirect, mode, 0, H, 0, direct ? (void *)alias : g.d_xrgb, direct ? pitch_bytes : W * 4,
                                       out_rgb ? g.d_rgb : nullptr, out_index ? g.d_index : nullptr,
                                       out_distance ? g.d_zinv : nullptr, out_position ? g.d_pos : nullptr))) return rc;
-    if ((rc = copy_plane_interior(out_xrgb, pitch_bytes, g.d_xrgb, W * 4, W, H))) return rc;
+    if (!direct && (rc = copy_plane_interior(out_xrgb, pitch_bytes, g.d_xrgb, W * 4, W, H))) return rc;
     if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, g.d_rgb, px * 12, hipMemcpyDeviceToHost, g.stream));
     if (out_index) HIP_TRY(hipMemcpyAsync(out_index, g.d_index, px * 4, hipMemcpyDeviceToHost, g.stream));
     if (out_distance) HIP_TRY(hipMemcpyAsync(out_distance, g.d_zinv, px * 4, hipMemcpyDeviceToHost, g.stream));
@@ -1292,10 +1354,12 @@ extern "C" int mirt_rasterise(const mirt_view *view, const mirt_light *lights, i
     const int W = view->width, H = view->height;
     const size_t px = (size_t)W * H;
     if ((rc = ensure_staging(px, out_rgb != nullptr, out_index != nullptr, out_zinv != nullptr))) return rc;
-    if ((rc = mirt_rasterise_device(view, lights, nlights, indirect, 0, H, 0, g.d_xrgb, W * 4, out_rgb ? g.d_rgb : nullptr,
-                                    out_zinv ? g.d_zinv : nullptr, out_index ? g.d_index : nullptr))) return rc;
+    char *alias = registered_alias(out_xrgb, (size_t)pitch_bytes, H);
+    const bool direct = alias && host_direct();
+    if ((rc = mirt_rasterise_device(view, lights, nlights, indirect, 0, H, 0, direct ? (void *)alias : g.d_xrgb, direct ? pitch_bytes : W * 4,
+                                    out_rgb ? g.d_rgb : nullptr, out_zinv ? g.d_zinv : nullptr, out_index ? g.d_index : nullptr))) return rc;
     // the rasteriser's Update() paints the whole surface (rasteriser.cpp:190): every word is written
-    HIP_TRY(hipMemcpy2DAsync(out_xrgb, pitch_bytes, g.d_xrgb, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, g.stream));
+    if (!direct) HIP_TRY(hipMemcpy2DAsync(out_xrgb, pitch_bytes, g.d_xrgb, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, g.stream));
     if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, g.d_rgb, px * 12, hipMemcpyDeviceToHost, g.stream));
     if (out_zinv) HIP_TRY(hipMemcpyAsync(out_zinv, g.d_zinv, px * 4, hipMemcpyDeviceToHost, g.stream));
     if (out_index) HIP_TRY(hipMemcpyAsync(out_index, g.d_index, px * 4, hipMemcpyDeviceToHost, g.stream));

@@ -21,7 +21,7 @@ EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
     "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
-    "mirt_rasterise_device", "mirt_get_stats",
+    "mirt_rasterise_device", "mirt_get_stats", "mirt_surface_register", "mirt_surface_unregister",
 )
 
 
@@ -80,6 +80,8 @@ def load():
     lib.mirt_rasterise_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                           _vp, C.c_int, _vp, _vp, _vp]
     lib.mirt_get_stats.argtypes = [C.POINTER(Stats)]
+    lib.mirt_surface_register.argtypes = [_vp, C.c_size_t]
+    lib.mirt_surface_unregister.argtypes = [_vp]
     _lib = lib
     return lib
 
@@ -133,6 +135,15 @@ def init(device=0):
 def shutdown():
     if _lib is not None:
         _lib.mirt_shutdown()
+
+
+def surface_register(arr):
+    """Pins and maps a host surface (numpy array): frames rendered into it skip the staging copy (mirt_surface_register)."""
+    _check(load().mirt_surface_register(_ptr(arr), arr.nbytes))
+
+
+def surface_unregister(arr):
+    _check(load().mirt_surface_unregister(_ptr(arr)))
 
 
 def set_profiling(on):

@@ -112,6 +112,19 @@ MIRT_API void *mirt_stream(void);
  * writes (origin and bin tables, raster keys, depth-of-field planes, counters) exists once per stream. */
 MIRT_API int mirt_set_frames_in_flight(int frames);
 
+/* ---- host surfaces --------------------------------------------------------------------------------- */
+
+/* The surface PutPixelSDL writes (SDL_Surface::pixels of InitializeSDL's SDL_SetVideoMode, SDLauxiliary.h:31-52) is ordinary
+ * pageable memory; a frame copied into it is staged by the runtime at about half the link rate.  Registering it once --
+ * pixels, h * pitch bytes -- pins and maps it: mirt_raytrace / mirt_rasterise / their _ex forms then deliver every frame whose
+ * out_xrgb rows lie inside a registered surface by one DMA copy into the pinned pages (MIRT_HOST_PATH=direct: the render
+ * kernels store the XRGB words straight into the mapped surface instead, no staging plane).  On the MI355X box of this
+ * repository's measurements neither beats the pageable path (the link gives 37-46 GB/s either way, see bench.py host_path);
+ * the calls exist for hosts whose pageable copies are slower.  The caller keeps the memory alive until
+ * mirt_surface_unregister / mirt_shutdown.  Up to 4 surfaces. */
+MIRT_API int mirt_surface_register(void *pixels, size_t bytes);
+MIRT_API int mirt_surface_unregister(void *pixels);
+
 /* ---- scene --------------------------------------------------------------------------------------- */
 
 /* Replaces the global `vector<Triangle> triangles` (raytracer.cpp:28, rasteriser.cpp:64): copies n
