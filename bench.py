@@ -168,7 +168,17 @@ class Env:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", local_rank))
+        if self.rehearsal:
+            os.environ["MIRT_COMM"] = "shm"                 # ranks share device 0: the library's host-staged loopback transport
         mirt.init(local_rank)
+        # The gather of the bands is the library's own (mirt_*_sharded: RCCL point-to-point inside libmirt.so, loaded at run
+        # time); torch.distributed only carries the 128-byte group id to the ranks.  MIRT_BENCH_GATHER=torch keeps the gather
+        # in Python (mirt/sharding.py, torch.distributed.gather) instead.
+        self.native = self.world > 1 and os.environ.get("MIRT_BENCH_GATHER", "native") != "torch"
+        if self.native:
+            ids = [mirt.comm_create_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            mirt.comm_init(ids[0], self.rank, self.world)
         self.dev = torch.device("cuda", local_rank)
         self.mirt_stream = torch.cuda.ExternalStream(mirt.load().mirt_stream(), device=self.dev)
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
@@ -222,8 +232,9 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     # Several GPUs: frames that render faster than a collective starts (the 30-triangle scenes) travel `batch` at a time --
     # one RCCL gather moves the bands of 32 consecutive frames; heavy frames (the soups: milliseconds) go one per gather.
     # Every frame is still rendered, gathered and assembled inside the timed region.
-    batch = 32 if (world > 1 and len(tris) < 1000) else 1
-    bands = BandGather(H, W, dev, depth=depth, batch=batch, via_host=env.rehearsal)
+    batch = 32 if (world > 1 and len(tris) < 1000 and kind == "rt") else 1
+    native = getattr(env, "native", False)
+    bands = BandGather(H, W, dev, depth=depth, batch=1 if native else batch, via_host=env.rehearsal)
     y0, y1 = bands.y0, bands.y1
     # One GPU: two frames in flight, alternating between the two bands (the library alternates between two streams, so the
     # next frame is dispatched while the previous one drains).  Several GPUs: one frame in flight per rank, the RCCL gather
@@ -257,10 +268,27 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
             bands.gather(k)
             gathered[k].record(comm_stream)
 
+    # native sharding: one library call renders this rank's band of `batch` consecutive views and gathers them on rank 0
+    root_frames = [torch.zeros((batch, H, W), dtype=torch.int32, device=dev) for _ in range(depth)] if (native and rank == 0) else None
+    sharded = {}
+
+    def sharded_fn(v0, k):
+        key = (v0, k)
+        if key not in sharded:
+            vs = [views[(v0 + b) % nviews] for b in range(batch)]
+            sharded[key] = mirt.prepared_sharded(kind, vs, LIGHT, INDIRECT, mode, 0, root_frames[k].data_ptr() if root_frames else None, W * 4)
+        return sharded[key]
+
     def frame():
         i = frame_no[0]
         frame_no[0] += 1
         v = i % nviews
+        if native:
+            if i % batch == 0:
+                if cullers is not None:
+                    cullers[v]()
+                sharded_fn(v, (i // batch) % depth)()
+            return
         if cullers is not None:
             cullers[v]()
         if world == 1:
@@ -280,6 +308,9 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     def finish_batch():
         """Gathers a batch the loop left incomplete and restarts the batch numbering."""
         last_batch[0] = batch
+        if native:                                       # (frames are issued in whole batches)
+            frame_no[0] = 0
+            return
         if world > 1 and frame_no[0] % batch:
             last_batch[0] = frame_no[0] % batch
             flush((frame_no[0] // batch) % depth)
@@ -322,7 +353,12 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
         else:
             mirt.rasterise_device(views[vlast], LIGHT, INDIRECT, 0, H, 0, full.data_ptr(), W * 4)
         mirt.sync()
-        got = bands.frames[last_batch[0] - 1] if batch > 1 else bands.frame
+        if native:
+            got = root_frames[((steps * fps_step - 1) // batch) % depth][(steps * fps_step - 1) % batch].clone()
+            if kind == "rt":                             # border words: never written by the ray tracer (received bands carry 0)
+                got[0, :] = full[0, :]; got[-1, :] = full[-1, :]; got[:, 0] = full[:, 0]; got[:, -1] = full[:, -1]
+        else:
+            got = bands.frames[last_batch[0] - 1] if batch > 1 else bands.frame
         same = bool(torch.equal(got, full))
         print("rehearsal %s: the last gathered frame is identical to the single-GPU frame: %s" % (name, same), file=sys.stderr, flush=True)
         if not same:
@@ -402,7 +438,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 "config": {"workload": name, "scene": "cornell-30" if scene[0] == "cornell" else "soup-%d-seed%d" % (scene[2], scene[1]),
                            "triangles": int(len(tris)), "width": W, "height": H, "lights": 1, "soft_shadow_samples": soft_samples, "aa_samples": aa, "dof_kernel": dof,
                            "primary_rays": W * H * aa * aa, "shadow_rays": int(shadow_frame), "mode": ["auto", "brute", "binned"][st["mode_used"]],
-                           "parallelism": ("bands%d+gather" % world + ("x%d" % batch if batch > 1 else "")) if world > 1 else "1gpu"},
+                           "parallelism": ("bands%d+%s" % (world, "rccl-p2p-gather(libmirt)" if native else "torch-gather") + ("x%d" % batch if batch > 1 else "")) if world > 1 else "1gpu"},
             })
             kt = kernel_ms.get("trace", 0.0)
             kname = {mirt.RT_BRUTE: ("k_rt_tile<" if aa > 1 else "k_rt_tile2") if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
@@ -447,7 +483,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 "metric": "frames/s (rasteriser)", "unit": "frames/s", "dtype": "f32", "value": round(nframes / dt, 3),
                 "config": {"workload": name, "scene": "cornell-30", "triangles": int(len(tris)), "visible_triangles": int((culled0 == 0).sum()),
                            "width": W, "height": H, "lights": 1, "dof_kernel": dof, "covered_pixels": covered,
-                           "parallelism": "bands%d+gather" % world if world > 1 else "1gpu"},
+                           "parallelism": ("bands%d+%s" % (world, "rccl-p2p-gather(libmirt)" if native else "torch-gather")) if world > 1 else "1gpu"},
             })
             # Dominant kernel: k_raster_resolve reads the 8-byte depth key of every pixel and writes the XRGB word; it also
             # re-zeroes the keys it consumed (8 more bytes per COVERED pixel), which replaced the per-frame clear.

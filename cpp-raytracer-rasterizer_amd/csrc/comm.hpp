@@ -1,0 +1,34 @@
+// comm.hpp -- band partition of a sharded frame and the gather of the bands on the root (comm.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+namespace mirt {
+
+constexpr int COMM_ID_BYTES = 128;      // == NCCL_UNIQUE_ID_BYTES
+
+// rows [y0, y1) of `rank` when `height` rows are split into `world` contiguous bands (sizes differ by at most one row)
+void band_of(int rank, int world, int height, int *y0, int *y1);
+
+struct Comm;
+// rank 0 creates the id (ncclGetUniqueId; a file-name prefix for the shm transport) and hands it to the other ranks
+bool comm_create_id(void *id128);
+Comm *comm_init(const void *id128, int rank, int world);      // collective; NULL on failure (comm_error(NULL))
+void comm_destroy(Comm *c);
+const char *comm_error(const Comm *c);
+int comm_rank(const Comm *c);
+int comm_world(const Comm *c);
+
+// The messages of one gather as offsets: on the root, `bytes` from rank `peer` land at root_offset of its frame buffer
+// (nviews frames of height * width * 4 bytes); on rank `peer`, they are the `bytes` at band_offset of its band buffer (nviews
+// bands of its rows).  Returns the number of pieces written (at most max_pieces); pure arithmetic.
+struct BandPiece { size_t root_offset, band_offset, bytes; int peer; };
+int band_gather_plan(int world, int root, int width, int height, int nviews, BandPiece *out, int max_pieces);
+
+// One message of the gather.  On the root: `bytes` from rank `peer` land at `ptr`; elsewhere: `bytes` at `ptr` go to the root.
+struct GatherPiece { void *ptr; size_t bytes; int peer; };
+// All pieces in one group on `stream` (RCCL: asynchronous, stream-ordered; shm: synchronous).
+bool comm_gather_bands(Comm *c, int root, const GatherPiece *pieces, int npieces, hipStream_t stream);
+
+}  // namespace mirt

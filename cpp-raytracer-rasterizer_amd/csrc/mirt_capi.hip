@@ -2,6 +2,7 @@
 // library stream, staging buffers and the per-call statistics.  No CPU fallback: without a gfx950 device
 // every compute entry point returns MIRT_ERR_NO_DEVICE.
 #include "bin_sort.hpp"
+#include "comm.hpp"
 #include "cull.hpp"
 #include "dof.hpp"
 #include "rt_common.hpp"
@@ -15,6 +16,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 namespace mirt {
 
@@ -172,6 +174,15 @@ struct Ctx {
     size_t cap_px = 0;
     RasterScratch raster[2];                     // one set of rasteriser scratch per stream (frames in flight)
 
+    // several GPUs: this process's place among the ranks that shard a frame, and its band buffers (two: the gather of one
+    // batch overlaps the render of the next)
+    Comm *comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_rendered = nullptr, ev_sent[2] = { nullptr, nullptr };
+    char *d_band[2] = { nullptr, nullptr };
+    size_t band_bytes[2] = { 0, 0 };
+    int band_slot = 0;
+
     // statistics of the last call
     mirt_stats stats = {};
     bool stats_pending = false;
@@ -250,6 +261,7 @@ hipError_t sync_all()
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2; i++)
         if (g.streams[i]) { const hipError_t r = hipStreamSynchronize(g.streams[i]); if (r != hipSuccess) e = r; }
+    if (g.comm_stream) { const hipError_t r = hipStreamSynchronize(g.comm_stream); if (r != hipSuccess) e = r; }
     return e;
 }
 
@@ -1005,6 +1017,11 @@ extern "C" void mirt_shutdown(void)
                      (void *)g.dof[1].rgb, (void *)g.dof[1].fd, (void *)g.dof[1].xrgb, (void *)g.dof[1].index, (void *)g.dof[1].zinv })
         if (p) (void)hipFree(p);
     for (Ctx::HostSurface &r : g.surf) if (r.host) (void)hipHostUnregister(r.host);
+    if (g.comm_stream) (void)hipStreamSynchronize(g.comm_stream);
+    comm_destroy(g.comm);
+    for (int i = 0; i < 2; i++) { if (g.d_band[i]) (void)hipFree(g.d_band[i]); if (g.ev_sent[i]) (void)hipEventDestroy(g.ev_sent[i]); }
+    if (g.ev_rendered) (void)hipEventDestroy(g.ev_rendered);
+    if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);
     raster_scratch_free(g.raster[0]);
     raster_scratch_free(g.raster[1]);
     for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
@@ -1404,3 +1421,139 @@ extern "C" int mirt_get_stats(mirt_stats *out)
     *out = g.stats;
     return MIRT_OK;
 }
+
+// ---- several GPUs of one node: frames shard by row bands, one process per GPU ----------------------
+
+extern "C" int mirt_band_of(int rank, int world, int height, int *y0, int *y1)
+{
+    if (world < 1 || rank < 0 || rank >= world || height < 0 || !y0 || !y1) return fail(MIRT_ERR_INVALID_ARGUMENT, "band of rank %d / %d, %d rows", rank, world, height);
+    band_of(rank, world, height, y0, y1);
+    return MIRT_OK;
+}
+
+extern "C" int mirt_band_plan(int world, int root, int width, int height, int nviews, uint64_t *root_offset, uint64_t *band_offset,
+                              uint64_t *bytes, int32_t *peer, int max_pieces)
+{
+    if (world < 1 || root < 0 || root >= world || width < 1 || height < 0 || nviews < 1 || max_pieces < 0)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "band plan: world %d root %d frame %dx%d views %d", world, root, width, height, nviews);
+    std::vector<BandPiece> plan((size_t)std::max(max_pieces, 1));
+    const int n = band_gather_plan(world, root, width, height, nviews, plan.data(), max_pieces);
+    for (int i = 0; i < n && i < max_pieces; i++) {
+        if (root_offset) root_offset[i] = plan[i].root_offset;
+        if (band_offset) band_offset[i] = plan[i].band_offset;
+        if (bytes) bytes[i] = plan[i].bytes;
+        if (peer) peer[i] = plan[i].peer;
+    }
+    return n;
+}
+
+extern "C" int mirt_comm_create_id(void *id128)
+{
+    if (!id128) return fail(MIRT_ERR_INVALID_ARGUMENT, "id must not be NULL");
+    if (!comm_create_id(id128)) return fail(MIRT_ERR_HIP, "%s", comm_error(nullptr));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_comm_init(const void *id128, int rank, int world)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!id128) return fail(MIRT_ERR_INVALID_ARGUMENT, "id must not be NULL");
+    if (g.comm) { HIP_TRY(sync_all()); comm_destroy(g.comm); g.comm = nullptr; }
+    g.comm = comm_init(id128, rank, world);
+    if (!g.comm) return fail(MIRT_ERR_HIP, "%s", comm_error(nullptr));
+    if (!g.comm_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_rendered, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&g.ev_sent[i], hipEventDisableTiming));
+    }
+    return MIRT_OK;
+}
+
+extern "C" int mirt_comm_shutdown(void)
+{
+    if (!g.init || !g.comm) return MIRT_OK;
+    HIP_TRY(sync_all());
+    comm_destroy(g.comm);
+    g.comm = nullptr;
+    return MIRT_OK;
+}
+
+// `render(view, y0, y1, row_origin, d_xrgb, pitch)` enqueues one band of one frame on g.stream.
+template <class Render>
+static int render_sharded(const mirt_view *views, int nviews, int root, void *d_frames, int pitch_bytes, Render render)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!views || nviews < 1) return fail(MIRT_ERR_INVALID_ARGUMENT, "need at least one view");
+    const int W = views[0].width, H = views[0].height;
+    for (int v = 1; v < nviews; v++)
+        if (views[v].width != W || views[v].height != H) return fail(MIRT_ERR_INVALID_ARGUMENT, "the views of one call must share a frame size");
+    if (W < 1 || H < 1) return fail(MIRT_ERR_INVALID_ARGUMENT, "frame size %dx%d", W, H);
+    const int world = g.comm ? comm_world(g.comm) : 1, rank = g.comm ? comm_rank(g.comm) : 0;
+    if (root < 0 || root >= world) return fail(MIRT_ERR_INVALID_ARGUMENT, "root %d outside [0,%d)", root, world);
+    if (rank == root && !d_frames) return fail(MIRT_ERR_INVALID_ARGUMENT, "the root's frame buffer must not be NULL");
+    if (rank == root && (pitch_bytes < W * 4 || (pitch_bytes & 3))) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, W);
+    if (world > 1 && rank == root && pitch_bytes != W * 4) return fail(MIRT_ERR_INVALID_ARGUMENT, "a sharded frame needs a dense root buffer (pitch == 4 * width)");
+    if (world > 1 && g.in_flight != 1) return fail(MIRT_ERR_INVALID_ARGUMENT, "sharded frames overlap through the band buffers: use mirt_set_frames_in_flight(1)");
+    int y0, y1;
+    band_of(rank, world, H, &y0, &y1);
+    const size_t frame_bytes = (size_t)H * (size_t)pitch_bytes;
+    if (world == 1) {
+        for (int v = 0; v < nviews; v++)
+            if ((rc = render(&views[v], 0, H, 0, static_cast<char *>(d_frames) + (size_t)v * frame_bytes, pitch_bytes))) return rc;
+        return MIRT_OK;
+    }
+    const size_t band_row = (size_t)W * 4, my_bytes = (size_t)(y1 - y0) * band_row;
+    const int slot = g.band_slot;
+    g.band_slot ^= 1;
+    if (rank == root) {
+        // the root's own rows are rendered in place; the other bands arrive straight at their rows
+        for (int v = 0; v < nviews; v++)
+            if ((rc = render(&views[v], y0, y1, 0, static_cast<char *>(d_frames) + (size_t)v * frame_bytes, pitch_bytes))) return rc;
+    } else {
+        const size_t need = my_bytes * (size_t)nviews;
+        HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_sent[slot], 0));         // the gather that last read this buffer has finished
+        if (need > g.band_bytes[slot]) {
+            HIP_TRY(hipStreamSynchronize(g.comm_stream));
+            if (g.d_band[slot]) (void)hipFree(g.d_band[slot]);
+            g.d_band[slot] = nullptr; g.band_bytes[slot] = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&g.d_band[slot]), need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "band buffer (%zu bytes)", need);
+            HIP_TRY(hipMemsetAsync(g.d_band[slot], 0, need, g.stream));   // the border words the ray tracer never writes travel as 0
+            g.band_bytes[slot] = need;
+        }
+        for (int v = 0; v < nviews; v++)
+            if ((rc = render(&views[v], y0, y1, y0, g.d_band[slot] + (size_t)v * my_bytes, (int)band_row))) return rc;
+    }
+    // the one exchange step: every band to the root, on the communication stream, overlapping the next call's render
+    HIP_TRY(hipEventRecord(g.ev_rendered, g.stream));
+    HIP_TRY(hipStreamWaitEvent(g.comm_stream, g.ev_rendered, 0));
+    std::vector<BandPiece> plan((size_t)world * nviews);
+    const int np = band_gather_plan(world, root, W, H, nviews, plan.data(), (int)plan.size());
+    std::vector<GatherPiece> pieces;
+    for (int i = 0; i < np; i++) {
+        if (rank == root) pieces.push_back({ static_cast<char *>(d_frames) + plan[i].root_offset, plan[i].bytes, plan[i].peer });
+        else if (plan[i].peer == rank) pieces.push_back({ g.d_band[slot] + plan[i].band_offset, plan[i].bytes, root });
+    }
+    if (!pieces.empty() && !comm_gather_bands(g.comm, root, pieces.data(), (int)pieces.size(), g.comm_stream))
+        return fail(MIRT_ERR_HIP, "%s", comm_error(g.comm));
+    HIP_TRY(hipEventRecord(g.ev_sent[slot], g.comm_stream));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_raytrace_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,
+                                     int mode, int root, void *d_frames, int pitch_bytes)
+{
+    return render_sharded(views, nviews, root, d_frames, pitch_bytes, [&](const mirt_view *v, int y0, int y1, int origin, void *dst, int pitch) {
+        return mirt_raytrace_device(v, lights, nlights, indirect, mode, y0, y1, origin, dst, pitch, nullptr, nullptr);
+    });
+}
+
+extern "C" int mirt_rasterise_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,
+                                      int root, void *d_frames, int pitch_bytes)
+{
+    return render_sharded(views, nviews, root, d_frames, pitch_bytes, [&](const mirt_view *v, int y0, int y1, int origin, void *dst, int pitch) {
+        return mirt_rasterise_device(v, lights, nlights, indirect, y0, y1, origin, dst, pitch, nullptr, nullptr, nullptr);
+    });
+}
+

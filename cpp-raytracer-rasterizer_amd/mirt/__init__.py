@@ -22,6 +22,7 @@ EXPORTS = (
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
     "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats", "mirt_surface_register", "mirt_surface_unregister",
+    "mirt_band_of", "mirt_band_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
 )
 
 
@@ -82,6 +83,12 @@ def load():
     lib.mirt_get_stats.argtypes = [C.POINTER(Stats)]
     lib.mirt_surface_register.argtypes = [_vp, C.c_size_t]
     lib.mirt_surface_unregister.argtypes = [_vp]
+    lib.mirt_band_of.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mirt_band_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]
+    lib.mirt_comm_create_id.argtypes = [_vp]
+    lib.mirt_comm_init.argtypes = [_vp, C.c_int, C.c_int]
+    lib.mirt_raytrace_sharded.argtypes = [C.POINTER(View), C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int]
+    lib.mirt_rasterise_sharded.argtypes = [C.POINTER(View), C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int]
     _lib = lib
     return lib
 
@@ -336,6 +343,67 @@ def prepared_rasterise_device(view, lights7, indirect, y0, y1, row_origin, d_xrg
     fn = lib.mirt_rasterise_device
 
     def launch(_keep=(view, larr, ind)):
+        rc = fn(*args)
+        if rc:
+            _check(rc)
+    return launch
+
+
+# ---- several GPUs: band sharding with the gather inside the library ------------------------------------
+
+COMM_ID_BYTES = 128
+
+
+def band_of(rank, world, height):
+    y0, y1 = C.c_int(), C.c_int()
+    _check(load().mirt_band_of(int(rank), int(world), int(height), C.byref(y0), C.byref(y1)))
+    return y0.value, y1.value
+
+
+def band_plan(world, root, width, height, nviews):
+    """[(root_offset, band_offset, bytes, peer)] of one gather (mirt_band_plan)."""
+    n = load().mirt_band_plan(world, root, width, height, nviews, None, None, None, None, 0)
+    if n < 0:
+        _check(n)
+    ro, bo, by, pe = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.int32)
+    load().mirt_band_plan(world, root, width, height, nviews, _ptr(ro), _ptr(bo), _ptr(by), _ptr(pe), n)
+    return [(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(ro, bo, by, pe)]
+
+
+def comm_create_id():
+    buf = (C.c_char * COMM_ID_BYTES)()
+    _check(load().mirt_comm_create_id(buf))
+    return bytes(buf)
+
+
+def comm_init(comm_id, rank, world):
+    buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(comm_id)
+    _check(load().mirt_comm_init(buf, int(rank), int(world)))
+
+
+def comm_shutdown():
+    _check(load().mirt_comm_shutdown())
+
+
+def view_array(views):
+    arr = (View * len(views))()
+    for i, v in enumerate(views):
+        C.memmove(C.byref(arr[i]), C.byref(v), C.sizeof(View))
+    return arr
+
+
+def prepared_sharded(kind, views, lights7, indirect, mode, root, d_frames, pitch_bytes):
+    """Zero-argument callable: this rank's band of len(views) frames + the gather on `root` (mirt_*_sharded)."""
+    lib = load()
+    arr = view_array(views)
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32).copy()
+    if kind == "rt":
+        fn, args = lib.mirt_raytrace_sharded, (arr, len(views), larr, nl, _ptr(ind), int(mode), int(root), d_frames, int(pitch_bytes))
+    else:
+        fn, args = lib.mirt_rasterise_sharded, (arr, len(views), larr, nl, _ptr(ind), int(root), d_frames, int(pitch_bytes))
+
+    def launch(_keep=(arr, larr, ind)):
         rc = fn(*args)
         if rc:
             _check(rc)

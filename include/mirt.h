@@ -223,6 +223,43 @@ MIRT_API int mirt_rasterise_device(const mirt_view *view, const mirt_light *ligh
                                    const float *indirect, int y0, int y1, int row_origin,
                                    void *d_xrgb, int pitch_bytes, void *d_rgb, void *d_zinv, void *d_index);
 
+/* ---- several GPUs of one node: frames shard by row bands ----------------------------------------- */
+
+/* One process per GPU, as under torch.distributed / MPI; the reference itself is a single process (its only parallelism is
+ * OpenMP over rows, raytracer.cpp:557): these calls are what a sharded host loop adds around Draw().  Every rank uploads the
+ * same scene (the triangle list is replicated) and makes the same calls in the same order.
+ *
+ * mirt_band_of          rows [y0, y1) of `rank` when `height` rows are split into `world` contiguous bands (sizes differ by at
+ *                       most one row).  Pure arithmetic, no device needed.
+ * mirt_comm_create_id   rank 0: creates the 128-byte id of a new group (ncclGetUniqueId); the caller hands it to the other
+ *                       ranks by its own means (MPI_Bcast, torch.distributed.broadcast_object_list, a file).
+ * mirt_comm_init        every rank, after mirt_init: joins the group (collective).  Transport: RCCL point-to-point over xGMI,
+ *                       loaded at run time; MIRT_COMM=shm selects a host-staged loopback for ranks that share one GPU (tests).
+ * mirt_*_sharded        renders THIS rank's band of `nviews` consecutive frames (views[0..nviews) share a frame size) and
+ *                       gathers the XRGB bands on rank `root` -- the one exchange step of the path: each peer sends its rows
+ *                       straight to the root on its own link (a direct gather, not a ring), grouped into one collective per
+ *                       call, so frames that render in microseconds can travel many to a gather.  d_frames (device memory,
+ *                       required on the root only): nviews frames of height * pitch_bytes, pitch_bytes == 4 * width; frame i
+ *                       of the call is byte-identical to a single-GPU mirt_*_device frame (border words of received bands,
+ *                       which the ray tracer never writes, arrive as 0).  Asynchronous: the gather runs on a communication
+ *                       stream and overlaps the next call's render (two band buffers per rank); mirt_sync() waits for both.
+ *                       Without mirt_comm_init (or world == 1) the calls simply render whole frames.  Needs
+ *                       mirt_set_frames_in_flight(1). */
+#define MIRT_COMM_ID_BYTES 128
+MIRT_API int mirt_band_of(int rank, int world, int height, int *y0, int *y1);
+/* The messages of one gather (what mirt_*_sharded sends): piece i moves bytes[i] from band_offset[i] of rank peer[i]'s band
+ * buffer (nviews bands of its rows, 4 * width bytes per row) to root_offset[i] of the root's frame buffer.  Returns the number
+ * of pieces (writes at most max_pieces; arrays nullable).  Pure arithmetic, no device needed. */
+MIRT_API int mirt_band_plan(int world, int root, int width, int height, int nviews, uint64_t *root_offset, uint64_t *band_offset,
+                            uint64_t *bytes, int32_t *peer, int max_pieces);
+MIRT_API int mirt_comm_create_id(void *id128);
+MIRT_API int mirt_comm_init(const void *id128, int rank, int world);
+MIRT_API int mirt_comm_shutdown(void);
+MIRT_API int mirt_raytrace_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,
+                                   int mode, int root, void *d_frames, int pitch_bytes);
+MIRT_API int mirt_rasterise_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,
+                                    int root, void *d_frames, int pitch_bytes);
+
 /* Counters / timings of the most recent render call. */
 MIRT_API int mirt_get_stats(mirt_stats *out);
 

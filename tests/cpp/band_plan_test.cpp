@@ -1,0 +1,82 @@
+// World-size-2 (and 3, 5) test of the band partition and the gather plan of the sharded entry points, on the CPU: one
+// process per rank (fork), the bands travel through pipes exactly as the plan lists them (csrc/comm.cpp: band_of,
+// band_gather_plan -- the arithmetic mirt_*_sharded hands to RCCL), and the root checks every word of every frame.
+#include "../../cpp-raytracer-rasterizer_amd/csrc/comm.hpp"
+
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace mirt;
+
+static uint32_t pattern(int view, int y, int x) { return 0x9E3779B9u * (uint32_t)(view + 1) ^ (uint32_t)(y * 40503 + x * 65599 + 17); }
+
+static bool run(int world, int root, int W, int H, int nviews)
+{
+    std::vector<BandPiece> plan((size_t)world * nviews);
+    const int np = band_gather_plan(world, root, W, H, nviews, plan.data(), (int)plan.size());
+    std::vector<int> rd(world, -1), wr(world, -1);
+    std::vector<pid_t> pids;
+    for (int r = 0; r < world; r++) {
+        if (r == root) continue;
+        int fd[2];
+        if (pipe(fd) != 0) return false;
+        const pid_t pid = fork();
+        if (pid == 0) {                                   // rank r: render my band of every view, send the pieces the plan gives me
+            close(fd[0]);
+            int y0, y1;
+            band_of(r, world, H, &y0, &y1);
+            std::vector<uint32_t> band((size_t)nviews * (y1 - y0) * W);
+            for (int v = 0; v < nviews; v++)
+                for (int y = y0; y < y1; y++)
+                    for (int x = 0; x < W; x++) band[((size_t)v * (y1 - y0) + (y - y0)) * W + x] = pattern(v, y, x);
+            for (int i = 0; i < np; i++)
+                if (plan[i].peer == r) {
+                    const char *p = reinterpret_cast<const char *>(band.data()) + plan[i].band_offset;
+                    size_t left = plan[i].bytes;
+                    while (left) { const ssize_t n = write(fd[1], p, left); if (n <= 0) _exit(2); p += n; left -= (size_t)n; }
+                }
+            close(fd[1]);
+            _exit(0);
+        }
+        close(fd[1]);
+        rd[r] = fd[0];
+        pids.push_back(pid);
+    }
+    // the root: its own rows in place, the other bands where the plan puts them
+    std::vector<uint32_t> frames((size_t)nviews * H * W, 0xDEADBEEFu);
+    int y0, y1;
+    band_of(root, world, H, &y0, &y1);
+    for (int v = 0; v < nviews; v++)
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < W; x++) frames[((size_t)v * H + y) * W + x] = pattern(v, y, x);
+    bool ok = true;
+    for (int i = 0; i < np && ok; i++) {
+        char *p = reinterpret_cast<char *>(frames.data()) + plan[i].root_offset;
+        size_t left = plan[i].bytes;
+        while (left) { const ssize_t n = read(rd[plan[i].peer], p, left); if (n <= 0) { ok = false; break; } p += n; left -= (size_t)n; }
+    }
+    for (int r = 0; r < world; r++) if (rd[r] >= 0) close(rd[r]);
+    for (pid_t pid : pids) { int st = 0; waitpid(pid, &st, 0); ok = ok && WIFEXITED(st) && WEXITSTATUS(st) == 0; }
+    for (int v = 0; v < nviews && ok; v++)
+        for (int y = 0; y < H && ok; y++)
+            for (int x = 0; x < W; x++)
+                if (frames[((size_t)v * H + y) * W + x] != pattern(v, y, x)) { ok = false; fprintf(stderr, "world %d root %d: frame %d (%d,%d) wrong\n", world, root, v, x, y); break; }
+    // the bands tile [0, H) in rank order
+    int next = 0;
+    for (int r = 0; r < world; r++) { int a, b; band_of(r, world, H, &a, &b); ok = ok && a == next && b >= a && b - a <= H / world + 1; next = b; }
+    return ok && next == H;
+}
+
+int main()
+{
+    const int cases[][5] = { { 2, 0, 64, 48, 1 }, { 2, 1, 33, 7, 3 }, { 3, 0, 20, 10, 2 }, { 3, 2, 17, 2, 1 }, { 5, 3, 9, 23, 4 }, { 1, 0, 8, 8, 2 }, { 4, 0, 5, 3, 2 } };
+    for (const auto &c : cases)
+        if (!run(c[0], c[1], c[2], c[3], c[4])) { printf("FAILED world %d root %d %dx%d views %d\n", c[0], c[1], c[2], c[3], c[4]); return 1; }
+    printf("ok\n");
+    return 0;
+}

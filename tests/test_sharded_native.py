@@ -1,0 +1,133 @@
+"""The native sharded entry points (mirt_band_of / mirt_band_plan / mirt_comm_* / mirt_*_sharded, csrc/comm.cpp).
+
+Without a GPU: the band partition against mirt/sharding.py's, the gather plan applied to numpy buffers for 1..9 ranks and
+ragged frames, and a C++ program that runs the plan with one process per rank (world sizes 2, 3, 5) over pipes.
+-m gpu: two and three real processes on device 0 exchange their bands through the library's host-staged loopback transport
+(MIRT_COMM=shm; RCCL needs one GPU per rank, which the driver's 8-GPU run provides) and the root's frames must equal
+single-GPU frames byte for byte -- ray tracer (tile and binned kernels) and rasteriser, several frames per gather.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mirt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_band_of_matches_the_python_partition():
+    from mirt.sharding import band_of
+    for world in range(1, 10):
+        for H in (0, 1, 7, 8, 9, 540, 1080, 4320, 4321):
+            bands = [mirt.band_of(r, world, H) for r in range(world)]
+            assert bands == [band_of(r, world, H) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == H and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+    with pytest.raises(mirt.MirtError):
+        mirt.band_of(3, 3, 100)
+
+
+@pytest.mark.parametrize("world,root,W,H,nviews", [(1, 0, 5, 4, 2), (2, 0, 16, 9, 1), (2, 1, 7, 30, 3), (3, 1, 12, 10, 2), (8, 0, 6, 4321 // 100, 2), (9, 4, 3, 5, 1)])
+def test_gather_plan_assembles_frames(world, root, W, H, nviews):
+    """Applying the plan's byte moves to per-rank band buffers rebuilds every frame on the root."""
+    rng = np.random.RandomState(world * 100 + H)
+    full = rng.randint(0, 2 ** 32, (nviews, H, W), dtype=np.uint64).astype(np.uint32)
+    bands = {}
+    for r in range(world):
+        y0, y1 = mirt.band_of(r, world, H)
+        bands[r] = np.ascontiguousarray(full[:, y0:y1, :]).view(np.uint8).reshape(-1)
+    frames = np.zeros((nviews, H, W), np.uint32)
+    y0, y1 = mirt.band_of(root, world, H)
+    frames[:, y0:y1] = full[:, y0:y1]
+    flat = frames.view(np.uint8).reshape(-1)
+    plan = mirt.band_plan(world, root, W, H, nviews)
+    assert all(p[3] != root for p in plan)
+    for ro, bo, nbytes, peer in plan:
+        flat[ro:ro + nbytes] = bands[peer][bo:bo + nbytes]
+    assert np.array_equal(frames, full)
+    assert sum(p[2] for p in plan) == (H - (y1 - y0)) * W * 4 * nviews
+
+
+def test_cpp_world_size_2_partition_and_assembly(tmp_path):
+    """tests/cpp/band_plan_test.cpp: one process per rank, bands through pipes in plan order, every word checked."""
+    exe = str(tmp_path / "band_plan_test")
+    csrc = os.path.join(ROOT, "cpp-raytracer-rasterizer_amd", "csrc")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "band_plan_test.cpp"),
+                    os.path.join(csrc, "comm.cpp"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+RANK_CODE = r"""
+import os, sys, numpy as np
+sys.path[:0] = [%(pkg)r, %(tests)r]
+import mirt
+from devbuf import DeviceArray
+rank, world, root = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+idfile = sys.argv[4]
+mirt.init(0)
+if rank == 0:
+    cid = mirt.comm_create_id()
+    with open(idfile + ".tmp", "wb") as f: f.write(cid)
+    os.rename(idfile + ".tmp", idfile)
+else:
+    import time
+    while not os.path.exists(idfile): time.sleep(0.01)
+    cid = open(idfile, "rb").read()
+mirt.comm_init(cid, rank, world)
+L = np.array([[0.0, -0.5, -0.7, 1, 1, 1, 14]], np.float32)
+W, H = 200, 131
+ok = True
+for kind, scene in (("rt", "cornell"), ("rt", "soup"), ("raster", "cornell")):
+    tris = mirt.scene_cornell() if scene == "cornell" else np.concatenate([mirt.scene_cornell(), mirt.scene_soup(4, 3000, 0.1)])
+    views = [mirt.make_view((0.05 * i, 0, -2.6), mirt.rot_from_yaw(0.1 * i, 1.01 if kind == "raster" else 1.0), 70.0, W, H) for i in range(3)]
+    mirt.scene_upload(tris, mirt.cull(tris, views[0], 0) if kind == "raster" else None)
+    frames = DeviceArray((3, H, W), np.uint32, 0x33) if rank == root else None
+    mode = mirt.RT_BINNED if scene == "soup" else mirt.RT_AUTO
+    for rep in range(3):                     # several gathers in a row: both band buffers, events
+        mirt.prepared_sharded(kind, views, L, (0.2, 0.2, 0.2), mode, root, frames.ptr if frames else None, W * 4)()
+    mirt.sync()
+    if rank == root:
+        got = frames.read()
+        for i, v in enumerate(views):
+            ref = DeviceArray((H, W), np.uint32, 0x33)
+            if kind == "rt":
+                mirt.raytrace_device(v, L, (0.2, 0.2, 0.2), mode, 0, H, 0, ref.ptr, W * 4)
+            else:
+                mirt.rasterise_device(v, L, (0.2, 0.2, 0.2), 0, H, 0, ref.ptr, W * 4)
+            want = ref.read()
+            if kind == "rt":
+                # border words: the ray tracer never writes them; received bands carry 0 there, the root's own band the fill
+                want[0, :] = got[i][0, :]; want[-1, :] = got[i][-1, :]; want[:, 0] = got[i][:, 0]; want[:, -1] = got[i][:, -1]
+            if not np.array_equal(got[i], want):
+                ok = False
+                print("MISMATCH", kind, scene, "view", i, int((got[i] != want).sum()), flush=True)
+            assert (got[i][1:-1, 1:-1] != 0x33333333).any()
+mirt.comm_shutdown()
+mirt.shutdown()
+print("rank %%d done ok=%%s" %% (rank, ok), flush=True)
+sys.exit(0 if ok else 1)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 1)])
+def test_sharded_frames_through_the_loopback_transport(tmp_path, world, root):
+    code = RANK_CODE % {"pkg": os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), "tests": os.path.join(ROOT, "tests")}
+    env = dict(os.environ, MIRT_COMM="shm")
+    idfile = str(tmp_path / "comm_id")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(root), idfile], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
