@@ -48,7 +48,7 @@ struct RtTraceFrame {
     int cube_bins;
     int cam_shells;
 };
-template <bool AA, bool FLAT> __global__ void k_rt_trace(const RtTraceFrame);
+template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
 __global__ void k_geo_table(const float *, int, GeoRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, const GeoRow *, int, TriRow *);
 size_t rt_trace_lds_bytes();
@@ -626,12 +626,9 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     const int tile_rows = bs.frame0.j1 - bs.frame0.j0;
     const size_t lds = rt_trace_lds_bytes();
     k_begin(MIRT_K_TRACE);
-    static const bool flat = [] { const char *e = getenv("MIRT_SHADOW"); return e && !strcmp(e, "flat"); }();
     const dim3 tgrid((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2);
-    if (f.aa > 1 && flat) hipLaunchKernelGGL((k_rt_trace<true, true>), tgrid, dim3(256), lds, g.stream, tf);
-    else if (f.aa > 1) hipLaunchKernelGGL((k_rt_trace<true, false>), tgrid, dim3(256), lds, g.stream, tf);
-    else if (flat) hipLaunchKernelGGL((k_rt_trace<false, true>), tgrid, dim3(256), lds, g.stream, tf);
-    else hipLaunchKernelGGL((k_rt_trace<false, false>), tgrid, dim3(256), lds, g.stream, tf);
+    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace<true>, tgrid, dim3(256), lds, g.stream, tf);
+    else hipLaunchKernelGGL(k_rt_trace<false>, tgrid, dim3(256), lds, g.stream, tf);
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();

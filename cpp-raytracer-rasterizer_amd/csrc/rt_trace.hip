@@ -69,15 +69,26 @@ __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__res
 }
 
 // ---- the wave's LDS slice -----------------------------------------------------------------------------------------------
-constexpr int TR_STAGE = 64;          // candidates staged per chunk (one per lane)
-constexpr int TR_QUEUE = 128;         // queue slots: drained at 64, one step appends at most 64
+#ifndef MIRT_TR_STAGE
+#define MIRT_TR_STAGE 16
+#endif
+#ifndef MIRT_TR_DRAIN
+#define MIRT_TR_DRAIN 64
+#endif
+// The kernel is latency-bound (dependent LDS / global round trips per candidate and per drain), so what a wave keeps in LDS
+// decides how many waves hide each other's latency: 64 staged candidates + hit points cost 8.4 KB per wave = 4 workgroups
+// per CU and 103 us on the 100 k soup; 16 staged candidates and (u, v) instead of the hit point: 5.4 KB, 7 workgroups, 84 us.
+constexpr int TR_STAGE = MIRT_TR_STAGE;          // candidates staged per chunk (at most one per lane)
+constexpr int TR_DRAIN = MIRT_TR_DRAIN;          // the exact stage runs when this many pairs are queued (<= 64)
+constexpr int TR_QUEUE = TR_DRAIN + 64;          // queue slots: fewer than TR_DRAIN pairs are queued when a filter step appends at most 64
+static_assert(TR_DRAIN >= 1 && TR_DRAIN <= 64, "a drain hands one pair to each lane");
 
 struct TrWaveLds {
     float4 rows[TR_STAGE * 3];        // origin rows of the staged candidates
     float4 q[TR_QUEUE];               // {e1e2d, be2d, e1bd, e1e2b} of a queued (ray, candidate) pair
-    float4 pos[64];                   // hit point that belongs to best[]
     unsigned long long best[64];      // wavefront min-t key of the pixel's closest accepted hit (this sub-ray)
     uint2 qa[TR_QUEUE];               // {pixel (lane) of the pair, triangle index | row index}
+    float2 uv[64];                    // (u, v) of the hit that belongs to best[]: the hit point is rebuilt from them (:241)
     uint32_t idx[TR_STAGE];           // triangle ids of the staged candidates
     float thr[64];                    // shadow rays: r * 0.99f (:313)
     uint32_t flag[64];                // primary: some triangle was accepted (ClosestIntersection's return value); shadow: occluded
@@ -116,22 +127,22 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
                 // the pair that holds the record now also owns the stored hit point (keys are unique per pixel: one
                 // pair per triangle); a closer pair of a later drain overwrites both
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (s.best[a.x] == key) s.pos[a.x] = make_float4(p.x, p.y, p.z, 0.0f);
+                if (s.best[a.x] == key) s.uv[a.x] = make_float2(u, v);
             }
         }
     }
     wave_lds_fence();
 }
 
-// Drains 64 pairs and moves the rest of the queue to its front.
+// Drains TR_DRAIN pairs and moves the rest of the queue to its front.
 template <bool SHADOW>
 __device__ __forceinline__ void tr_drain_full(TrWaveLds &s, int lane, int &qn, const float4 *__restrict__ geo, int stride16, v3 start)
 {
-    tr_drain<SHADOW>(s, lane, 64, geo, stride16, start);
-    const int rest = qn - 64;
+    tr_drain<SHADOW>(s, lane, TR_DRAIN, geo, stride16, start);
+    const int rest = qn - TR_DRAIN;
     float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint2 a = make_uint2(0u, 0u);
-    if (lane < rest) { e = s.q[64 + lane]; a = s.qa[64 + lane]; }
+    if (lane < rest) { e = s.q[TR_DRAIN + lane]; a = s.qa[TR_DRAIN + lane]; }
     wave_lds_fence();
     if (lane < rest) { s.q[lane] = e; s.qa[lane] = a; }
     qn = rest;
@@ -150,7 +161,7 @@ struct RtTraceFrame {
     int cam_shells;                   // depth shells per camera bin: bin b's list is cam_off[b * cam_shells] .. cam_off[(b + 1) * cam_shells]
 };
 
-template <bool AA, bool FLAT>
+template <bool AA>
 __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
@@ -228,8 +239,8 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                             s.qa[at] = make_uint2((uint32_t)lane, s.idx[j]);
                         }
                         qn += __popcll(m);
-                        if (qn >= 64) {
-                            tr_drain_full<false>(s, lane, qn, geo4, 3, cam);
+                        if (qn >= TR_DRAIN) {
+                            do tr_drain_full<false>(s, lane, qn, geo4, 3, cam); while (qn >= TR_DRAIN);    // (one pass when TR_DRAIN == 64)
                             lane_best = min_t_dist(s.best[lane]);
                             tile_best = wave_max_f(ok ? lane_best : -FLT_MAX);
                             pm &= __ballot(!(my_near > tile_best));
@@ -244,8 +255,12 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
             const bool any = s.flag[lane] != 0u;           // ClosestIntersection's return value
             const float sd = min_t_dist(skey);
             if (any && best_d >= sd) {
-                const float4 sp = s.pos[lane];
-                best_d = sd; best_i = min_t_index(skey); pos = V3(sp.x, sp.y, sp.z);
+                // the hit point, rebuilt as the exact stage built it: pos = v0 + u*e1 + v*e2 (:241) -- same operands, same bits
+                const float2 suv = s.uv[lane];
+                best_d = sd; best_i = min_t_index(skey);
+                const float4 *gw = geo4 + (size_t)best_i * 3;
+                const float4 g0 = gw[0], g1 = gw[1], g2 = gw[2];
+                pos = add3(add3(V3(g0.x, g0.y, g0.z), scale3(V3(g0.w, g1.x, g1.y), suv.x)), scale3(V3(g1.z, g1.w, g2.x), suv.y));
             }
 
             const bool hit = ok && any;
@@ -260,61 +275,6 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                     v3 rd;
                     float r;
                     v3 D = light_term(f, k, pos, nDir, &rd, &r);
-                    if (FLAT) {
-                    // ---- shadow ray from the light along -rDir (:310): any accepted hit closer than 0.99 r occludes ----
-                    // The rays of a tile fall into ~8 different light-cube bins with lists of very different lengths, so a
-                    // lane walking its own list would leave most of the wave idle (round 1 and the first version of this
-                    // kernel: steps = the LONGEST list).  Instead the (ray, candidate) pairs of the whole wave are numbered
-                    // consecutively -- an exclusive scan of the list lengths -- and lane t of each round takes pair t: a
-                    // six-step search in the scanned starts finds its ray, whose direction and list base sit in LDS.
-                    wave_lds_fence();
-                    s.thr[lane] = r * 0.99f;                       // (:313)
-                    s.flag[lane] = 0u;
-                    uint32_t lbeg = 0, llen = 0;
-                    if (hit) {
-                        const uint32_t bin = cube_bin_of(rd, (uint32_t)k * 6u * (uint32_t)(tf.cube_bins * tf.cube_bins), tf.cube_bins);
-                        lbeg = tf.light_off[bin]; llen = tf.light_off[bin + 1] - lbeg;
-                    }
-                    uint32_t incl = llen;
-#pragma unroll
-                    for (int dd = 1; dd < 64; dd <<= 1) {
-                        const uint32_t o = __shfl_up(incl, dd);
-                        if (lane >= dd) incl += o;
-                    }
-                    const uint32_t npairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    s.idx[lane] = incl - llen;                     // first pair of this lane's ray
-                    s.pos[lane] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(lbeg));
-                    ntests += llen;
-                    wave_lds_fence();
-                    for (uint32_t t0 = 0; t0 < npairs; t0 += 64) {
-                        const uint32_t t = t0 + (uint32_t)lane;
-                        const bool valid = t < npairs;
-                        int ray = 0;                               // the largest ray whose first pair is <= t
-                        uint32_t first = 0;
-#pragma unroll
-                        for (int step = 32; step >= 1; step >>= 1) {
-                            const uint32_t st = s.idx[ray + step];
-                            if (st <= t) { ray += step; first = st; }
-                        }
-                        const float4 rr = s.pos[ray];
-                        const uint32_t e = __float_as_uint(rr.w) + (t - first);
-                        float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0;
-                        if (valid) { const float4 *src = lrow4 + (size_t)e * 6; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
-                        const TestDots td = test_dots(c0, c1, c2, V3(rr.x, rr.y, rr.z));    // negD = rDir (:310, :229)
-                        const bool pass = valid && maybe_hit(td);
-                        const unsigned long long m = __ballot(pass);
-                        if (m) {
-                            const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (pass) {
-                                s.q[at] = make_float4(td.den, td.pu, td.qv, c0.w);
-                                s.qa[at] = make_uint2((uint32_t)ray, e);
-                            }
-                            qn += __popcll(m);
-                            if (qn >= 64) tr_drain_full<true>(s, lane, qn, lrow4 + 3, 6, L);
-                        }
-                    }
-                    if (qn) { tr_drain<true>(s, lane, qn, lrow4 + 3, 6, L); qn = 0; }
-                    } else {
                     wave_lds_fence();
                     const float thr = r * 0.99f;                   // (:313)
                     s.thr[lane] = thr;
@@ -345,8 +305,8 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                                 s.qa[at] = make_uint2((uint32_t)lane, e);
                             }
                             qn += __popcll(m);
-                            if (qn >= 64) {
-                                tr_drain_full<true>(s, lane, qn, lrow4 + 3, 6, L);
+                            if (qn >= TR_DRAIN) {
+                                do tr_drain_full<true>(s, lane, qn, lrow4 + 3, 6, L); while (qn >= TR_DRAIN);
                                 occ = s.flag[lane] != 0u;                        // a lane found occluded stops walking
                             }
                         }
@@ -355,7 +315,6 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                         act = nact && !occ;
                     }
                     if (qn) { tr_drain<true>(s, lane, qn, lrow4 + 3, 6, L); qn = 0; }
-                    }
                     if (s.flag[lane] != 0u) D = V3(0.0f, 0.0f, 0.0f);           // occluded (:313-314); any-hit is exact
                     result = add3(result, D);                      // (:319)
                     if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
@@ -383,10 +342,8 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
         f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
 
-template __global__ void k_rt_trace<false, false>(const RtTraceFrame);
-template __global__ void k_rt_trace<true, false>(const RtTraceFrame);
-template __global__ void k_rt_trace<false, true>(const RtTraceFrame);
-template __global__ void k_rt_trace<true, true>(const RtTraceFrame);
+template __global__ void k_rt_trace<false>(const RtTraceFrame);
+template __global__ void k_rt_trace<true>(const RtTraceFrame);
 
 size_t rt_trace_lds_bytes() { return 4 * sizeof(TrWaveLds); }
 
