@@ -3,7 +3,7 @@
 // pairs of a frame, more than the binning itself).
 //
 // A bin id is at most ~23 bits and the consumers only need "all pairs of a bin are contiguous", so this is a two-level
-// counting sort keyed on what the data is.  bucket = bin >> shift, 64 .. 1024 consecutive bins (bucket_sort_shift):
+// counting sort keyed on what the data is.  bucket = bin >> shift, 256 .. 1024 consecutive bins (bucket_sort_shift):
 //   k_bin_pairs   (rt_binned.hip) counts the pairs per bucket while it stages them: an LDS histogram per flush, one global
 //                 atomic per (flush, non-empty bucket);
 //   k_bs_scatter  every workgroup scans the bucket counts for itself (LDS), then takes 4096 pairs at a time, ranks them per
@@ -18,12 +18,13 @@
 #include "bin_sort.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace mirt {
 
 constexpr int BS_PER_THREAD = 16;
 constexpr int BS_CHUNK = 256 * BS_PER_THREAD;
-constexpr int BS_LOCAL_PER_THREAD = 8;
+constexpr int BS_LOCAL_PER_THREAD = 16;
 
 // exclusive scan of v over the 256 threads of the workgroup; *total = sum
 __device__ __forceinline__ uint32_t bs_block_scan(uint32_t v, uint32_t *s_wave /* 4 */, uint32_t *total)
@@ -151,11 +152,14 @@ __global__ __launch_bounds__(256) void k_bs_local(const uint32_t *__restrict__ k
     }
 }
 
-// bins per bucket = 1 << shift: 64 where that keeps the bucket count (one LDS counter each, in k_bin_pairs and twice in
-// k_bs_scatter) within 8192, more for very many bins; more than 8192 buckets of 1024 bins is beyond this sort.
+// bins per bucket = 1 << shift: 256 (measured on the 0.5 M pairs of the 100 k soup's camera frame: scatter + local take 57 /
+// 38 / 28 / 25 us at 32 / 64 / 128 / 256 bins per bucket -- fewer buckets mean longer contiguous runs in the scatter's
+// output), more where that many buckets would not fit the LDS counters (8192); more than 8192 buckets of 1024 bins is beyond
+// this sort.  MIRT_BS_SHIFT overrides the minimum.
 int bucket_sort_shift(uint32_t nbins)
 {
-    int shift = 6;
+    static const int min_shift = [] { const char *e = getenv("MIRT_BS_SHIFT"); int v = e ? atoi(e) : 0; return (v >= 4 && v <= 10) ? v : 8; }();
+    int shift = min_shift;
     while (shift < 10 && ((nbins + 1u + (1u << shift) - 1u) >> shift) > 8192u) shift++;
     return shift;
 }

@@ -401,7 +401,9 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     // workgroups striding over the (256-triangle chunk, frame) work items: 8 per CU (36 KiB of LDS each, 4 resident; 1 M
     // triangles at 8K: 4.06 -> 3.53 ms per frame against 3 per CU); MIRT_BIN_WGS overrides
     static const int bin_wgs = [] { const char *e = getenv("MIRT_BIN_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 16) ? v : 8; }();
-    const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + 255) / 256) * bs.nframes, (long long)g.cu_count * bin_wgs));
+    static const int chunk_env = [] { const char *e = getenv("MIRT_BIN_CHUNK"); int v = e ? atoi(e) : 0; return (v == 64 || v == 256) ? v : 0; }();
+    bs.chunk_tris = chunk_env ? chunk_env : 256;        // (64 measured slower on the 100 k soup: 86 vs 74 us for the whole binning, more flushes)
+    const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + bs.chunk_tris - 1) / bs.chunk_tris) * bs.nframes, (long long)g.cu_count * bin_wgs));
     bs.counters = counter;
     // order the pairs by bin with the two-level counting sort on the bin id (bin_bucket_sort.hip: k_bin_pairs counts the pairs
     // per bucket, two more launches sort), or -- when the bins are too many for its LDS histograms, or MIRT_BIN_SORT=rocprim --

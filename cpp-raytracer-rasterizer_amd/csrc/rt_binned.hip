@@ -203,7 +203,11 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base, s_fill, s_valid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nchunks = (n + 255) / 256, nwork = nchunks * bs.nframes;
+    // triangles per work item: 256 (one per thread), or 64 when that leaves the chip under-filled -- a single camera frame of
+    // 100 k triangles is only 391 items of 256 for 256 CUs, each a serial ~10 us; with 64 the setup of an item occupies one
+    // wave and its flattened tests still use all four
+    const int chunk_tris = bs.chunk_tris;
+    const int nchunks = (n + chunk_tris - 1) / chunk_tris, nwork = nchunks * bs.nframes;
     if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
     if (bs.bucket_cnt)
         for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += 256) s_bucket[b] = 0u;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
 
     for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
         const int chunk = w / bs.nframes, frame = w - chunk * bs.nframes;
-        const uint32_t tri0 = (uint32_t)chunk * 256u, tri = tri0 + threadIdx.x;
+        const uint32_t tri0 = (uint32_t)chunk * (uint32_t)chunk_tris, tri = tri0 + threadIdx.x;
         const BinFrameDesc fr = bs.frames ? bs.frames[frame] : bs.frame0;
         BinFrameGrid gr;
         gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base; gr.nshell = (uint32_t)max(fr.nshell, 1);
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         int i_lo = 0, i_hi = -1, j_lo = 0, j_hi = -1;
         unsigned long long cells = 0;                     // huge items: level-0 cells (first 64) that may hold a hit
         uint32_t shell = 0;                               // depth shell of the triangle in this frame (orders the bins' lists)
-        if (tri < (uint32_t)n && fj1 > fj0) {
+        if ((int)threadIdx.x < chunk_tris && tri < (uint32_t)n && fj1 > fj0) {
             const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
             shell = bin_shell_of(fr, row.r1.w);
             TriBinFns t = make_bin_fns(row, fr);

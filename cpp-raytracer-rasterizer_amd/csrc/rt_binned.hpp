@@ -75,6 +75,7 @@ struct BinSet {
     uint32_t *bucket_cnt;         // nullable: pairs per bucket = bin >> bucket_shift, for the bucket sort (bin_bucket_sort.hip)
     uint32_t nbuckets;
     int bucket_shift;
+    int chunk_tris;               // triangles per work item of k_bin_pairs: 256 or 64
 };
 
 // The unsorted (bin, triangle) pair list k_bin_pairs writes and bin_sort.hip orders by bin.
