@@ -589,12 +589,12 @@ def main():
     steps = args.steps if args.steps is not None else 20
     warmup = args.warmup if args.warmup is not None else 3
     name = args.workload or "cornell1080"
-    target = 0.06 if args.mode != "brute" else 0.0
+    target = 0.1 if args.mode != "brute" else 0.0
     out = run_workload(env, name, steps, warmup, args.mode, not args.static_camera, not args.no_cpu_baseline, target_s=target)
     if args.workload is None and not args.no_sub_results and env.world == 1:
         subs = {}
         for sub in SUB_RESULTS:
-            r = run_workload(env, sub, max(4, steps // 2), 1, "auto", not args.static_camera, not args.no_cpu_baseline, target_s=0.04, extras=False)
+            r = run_workload(env, sub, max(4, steps // 2), 1, "auto", not args.static_camera, not args.no_cpu_baseline, target_s=0.07, extras=False)
             if r is not None:
                 subs[sub] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_frame", "frames_per_s", "frames_per_step", "steps", "timed_region_s",
                                                "kernel_ms_rank0", "config", "roofline", "cpu_baseline") if k in r}
