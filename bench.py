@@ -451,7 +451,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None if ach is None else round(ach / PEAK_FP32_TFLOPS, 4),
                                "traffic": measured_traffic(name, [kname]) if world == 1 else None,
                                "traffic_source": "profiles/%s_hbm_traffic.json (rocprofv3 PMC, bytes per launch)" % ROUND,
-                               "tests_per_launch": int(tests_rank), "kernel_ms": round(kt, 5),
+                               "tests_per_launch": int(tests_rank), "candidates_per_launch": int(st["candidates"]), "kernel_ms": round(kt, 5),
                                "kernel_ms_mode": "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera" % (in_flight, "moving" if moving else "static"),
                                "reference_tests_per_launch": int(rays_rank * len(tris)),
                                "reference_equivalent_tflops": None if kt <= 0 else round(rays_rank * len(tris) * FLOP_PER_TEST / (kt * 1e-3) / 1e12, 3),
@@ -468,6 +468,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 out["roofline"]["valu_issue"] = {"instructions_per_launch": int(insts), "achieved": round(ipc, 4), "peak": ISSUE_CEILING,
                                                  "unit": "wave-instr/clk/SIMD", "frac": round(ipc / ISSUE_CEILING, 4),
                                                  "lane_slots_per_test": round(insts * 64.0 / max(tests_rank, 1.0), 1),
+                                                 "lane_slots_per_candidate": round(insts * 64.0 / max(float(st["candidates"]), 1.0), 1),
                                                  "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}
             algo_bytes = 4.0 * W * (y1 - y0) + 60.0 * len(tris)
             if kt > 0:

@@ -43,14 +43,14 @@ struct RtTraceFrame {
     const uint32_t *cam_entries;
     const GeoRow *geo;
     const uint32_t *light_off;
-    const TriRow *light_rows;
+    const LightRow *light_rows;
     int tiles_x;
     int cube_bins;
     int cam_shells;
 };
 template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
 __global__ void k_geo_table(const float *, int, GeoRow *);
-__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, const GeoRow *, int, TriRow *);
+__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *);
 size_t rt_trace_lds_bytes();
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
 __global__ void k_cull(const float *, int, const CullParams, uint8_t *);
@@ -112,7 +112,7 @@ struct LightCache {
     BinFrameDesc *d_frames = nullptr;            // 6 x nl frame descriptors
     uint32_t *d_off = nullptr;                   // nbins + 1
     uint32_t cap_bins = 0, nbins = 0;
-    TriRow *d_rows = nullptr;                    // expanded candidates in bin order
+    LightRow *d_rows = nullptr;                  // expanded candidates in bin order
     uint32_t cap_rows = 0, nrows = 0;
     float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
     uint32_t *d_counter = nullptr;               // pair counter of the build
@@ -533,7 +533,7 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
         C.nrows = npairs;
         if (npairs)
             hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((npairs + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.d_geo, g.n, C.d_rows);
+                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.n, C.d_rows);
         HIP_TRY(hipGetLastError());
         S.bin_key_valid = false;                             // the stream's pair list now holds the light pass
     } else {
@@ -1405,13 +1405,15 @@ extern "C" int mirt_get_stats(mirt_stats *out)
         } else if (g.pending_is_rt) {
             static unsigned long long shard[HIT_SHARDS * HIT_SHARD_STRIDE];
             HIP_TRY(hipMemcpy(shard, g.d_hits, sizeof shard, hipMemcpyDeviceToHost));
-            unsigned long long hits = 0, tests = 0;
-            for (int i = 0; i < HIT_SHARDS; i++) { hits += shard[i * HIT_SHARD_STRIDE]; tests += shard[i * HIT_SHARD_STRIDE + 1]; }
+            unsigned long long hits = 0, tests = 0, cands = 0;
+            for (int i = 0; i < HIT_SHARDS; i++) { hits += shard[i * HIT_SHARD_STRIDE]; tests += shard[i * HIT_SHARD_STRIDE + 1]; cands += shard[i * HIT_SHARD_STRIDE + 2]; }
             g.stats.tests = tests;
+            g.stats.candidates = cands;
             g.stats.primary_rays = g.pending_primary;
             g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
             if (g.stats.mode_used == MIRT_RT_BRUTE && !g.pending_counted)      // every ray tests every triangle
                 g.stats.tests = (g.stats.primary_rays + g.stats.shadow_rays) * (uint64_t)g.n;
+            if (g.stats.candidates == 0) g.stats.candidates = g.stats.tests;        // kernels that test every candidate they are offered
         }
         g.stats_pending = false;
         (void)hipGetLastError();                 // an event pair a frame never recorded (no clear needed, ...) leaves hipErrorInvalidHandle

@@ -59,9 +59,11 @@ __device__ __forceinline__ uint32_t bin_shell_of(const BinFrameDesc &fr, float n
 // Geometry row of a triangle: {v0.xyz, e1.x | e1.yz, e2.xy | e2.z, 0, 0, 0} -- what the accept path needs to rebuild the hit
 // point (raytracer.cpp:216-217, :241).  One per triangle (k_geo_table, rt_trace.hip).
 struct GeoRow { float4 g0, g1, g2; };
-// A shadow-ray candidate expanded in light-cube bin order: origin row of the triangle for that light + geometry row.
-struct TriRow { OriginRow o; GeoRow g; };
-static_assert(sizeof(TriRow) == 96, "expanded row must be 96 bytes");
+// A shadow-ray candidate expanded in light-cube bin order: the origin row of the triangle for that light, with the triangle's
+// index in the one slot an origin row leaves free (r2.w, as bits) -- what the exact stage needs to find the geometry row.
+// (Round 2 first stored {origin row, geometry row}, 96 bytes: 250 MB of reads per 1080p frame of the 100 k soup, half of them
+// geometry that only the few accepted pairs ever look at.)
+typedef OriginRow LightRow;
 
 struct BinSet {
     const BinFrameDesc *frames;   // device array of nframes descriptors, or NULL: the single frame `frame0` below

@@ -258,14 +258,30 @@ __device__ __forceinline__ int min_t_index(unsigned long long key) { return (int
 __device__ __forceinline__ float min_t_dist(unsigned long long key) { return __uint_as_float((uint32_t)(key >> 32)); }
 constexpr unsigned long long MIN_T_NONE = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // FLT_MAX, "index -1"
 
+// DPP reduction (no LDS traffic, unlike a __shfl_xor butterfly, which is ds_bpermute): four row_shr steps fold each row of 16
+// lanes into its lane 15, row_bcast:15 / row_bcast:31 carry the row results into lane 63 (lanes a step has no source for keep
+// their own value), v_readlane makes the minimum wave-uniform.  The two halves of the 64-bit key move in lockstep.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_min_step(unsigned long long key)
+{
+    const int lo = (int)(uint32_t)key, hi = (int)(uint32_t)(key >> 32);
+    const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < key ? o : key;
+}
+
 __device__ __forceinline__ unsigned long long wave_min_key(unsigned long long key)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_xor(key, d);
-        key = o < key ? o : key;
-    }
-    return key;       // every lane holds the wave minimum
+    key = dpp_min_step<0x111, 0xf>(key);      // row_shr:1
+    key = dpp_min_step<0x112, 0xf>(key);      // row_shr:2
+    key = dpp_min_step<0x114, 0xf>(key);      // row_shr:4
+    key = dpp_min_step<0x118, 0xf>(key);      // row_shr:8
+    key = dpp_min_step<0x142, 0xa>(key);      // row_bcast:15 into rows 1 and 3
+    key = dpp_min_step<0x143, 0xc>(key);      // row_bcast:31 into rows 2 and 3
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;       // every lane holds the wave minimum
 }
 
 // ray-triangle tests a wave executed (second word of the shard); used for the roofline of the binned path
@@ -284,6 +300,17 @@ __device__ __forceinline__ void store_intersection(const RtFrame &f, size_t px, 
 {
     if (f.dist) f.dist[px] = best_i >= 0 ? best_d : 3.402823466e+38f;
     if (f.pos) st3(f.pos + 3 * px, best_i >= 0 ? pos : V3(0.0f, 0.0f, 0.0f));
+}
+
+// candidates a wave OFFERED to its rays (third word of the shard): list entries x rays, whether the filter ran on them or a
+// `near` bound skipped them -- what round 1's kernels counted as tests, kept so that the two rounds compare like for like
+__device__ __forceinline__ void count_candidates(const RtFrame &f, unsigned lane_candidates)
+{
+    const unsigned total = wave_sum(lane_candidates);
+    if ((threadIdx.x & 63) == 0 && total) {
+        const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x + (threadIdx.x >> 6) * 61u) % HIT_SHARDS;
+        atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 2, (unsigned long long)total);
+    }
 }
 
 // Per-light shading term D of DirectLight (raytracer.cpp:294-304) before the shadow test.

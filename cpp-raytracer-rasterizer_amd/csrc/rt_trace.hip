@@ -48,22 +48,21 @@ __global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tri
     geo[t] = g;
 }
 
-// rows[p] = {origin row of triangle entries[p] for the light its bin belongs to, geometry row}: the sorted pair list of
-// the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.  bin_off[k * bins_per_light] is
-// where the pairs of light k start.
+// rows[p] = origin row of triangle entries[p] for the light its bin belongs to, with the triangle index in r2.w: the sorted
+// pair list of the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.
+// bin_off[k * bins_per_light] is where the pairs of light k start.
 __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ entries,
                                                            int nlights, uint32_t bins_per_light,
-                                                           const OriginRow *__restrict__ light_tab, const GeoRow *__restrict__ geo, int n,
-                                                           TriRow *__restrict__ rows)
+                                                           const OriginRow *__restrict__ light_tab, int n,
+                                                           LightRow *__restrict__ rows)
 {
     const uint32_t total = bin_off[(size_t)nlights * bins_per_light];
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
         int k = 0;
         while (k + 1 < nlights && bin_off[(size_t)(k + 1) * bins_per_light] <= p) k++;
         const uint32_t tri = entries[p];
-        TriRow r;
-        r.o = light_tab[(size_t)k * n + tri];
-        r.g = geo[tri];
+        LightRow r = light_tab[(size_t)k * n + tri];
+        r.r2.w = __uint_as_float(tri);
         rows[p] = r;
     }
 }
@@ -155,7 +154,7 @@ struct RtTraceFrame {
     const uint32_t *cam_entries;      // triangle ids ordered by camera bin
     const GeoRow *geo;                // n geometry rows (k_geo_table)
     const uint32_t *light_off;        // light-cube bins of all light positions: first row of each, nlights*6*B*B + 1
-    const TriRow *light_rows;         // expanded candidates ordered by light-cube bin (k_expand_light_rows)
+    const LightRow *light_rows;       // expanded candidates ordered by light-cube bin (k_expand_light_rows)
     int tiles_x;                      // camera bins per row
     int cube_bins;                    // B: light-cube bins per face side
     int cam_shells;                   // depth shells per camera bin: bin b's list is cam_off[b * cam_shells] .. cam_off[(b + 1) * cam_shells]
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
     float best_d = FLT_MAX;                                // Update() reset (:335-339), once per frame
     int best_i = -1;
     v3 pos = V3(0.0f, 0.0f, 0.0f), avg = V3(0.0f, 0.0f, 0.0f);
-    unsigned ntests = 0;
+    unsigned ntests = 0, ncand = 0;
     int qn = 0;                                            // queued pairs (wave-uniform)
 
     float y1 = aa_start(y, rs);                            // :566-569
@@ -205,6 +204,7 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
             // most of a list is skipped.  The records are only updated by drains, i.e. the bounds lag -- never the result.
             s.best[lane] = MIN_T_NONE;
             s.flag[lane] = 0u;
+            if (ok) ncand += cend - cbeg;
             float lane_best = FLT_MAX;                     // distance of the sub-ray's record so far
             float tile_best = FLT_MAX;                     // max of lane_best over the tile's pixels (wave-uniform)
             for (uint32_t base = cbeg; base < cend; base += TR_STAGE) {
@@ -285,13 +285,14 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                         e = tf.light_off[bin]; end = tf.light_off[bin + 1];
                     }
                     bool act = e < end;
+                    ncand += end - e;
                     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0;
-                    if (act) { const float4 *src = lrow4 + (size_t)e * 6; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
+                    if (act) { const float4 *src = lrow4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
                     while (__ballot(act)) {
                         // request the next row before this one is tested
                         const bool nact = act && (e + 1 < end);
                         float4 n0 = c0, n1 = c1, n2 = c2;
-                        if (nact) { const float4 *src = lrow4 + (size_t)(e + 1) * 6; n0 = src[0]; n1 = src[1]; n2 = src[2]; }
+                        if (nact) { const float4 *src = lrow4 + (size_t)(e + 1) * 3; n0 = src[0]; n1 = src[1]; n2 = src[2]; }
                         const TestDots td = test_dots(c0, c1, c2, rd);           // negD = rDir (:310, :229)
                         // a candidate none of whose points is closer to the light than 0.99 r cannot occlude (:313)
                         const bool pass = act && !(c1.w > thr) && maybe_hit(td);
@@ -302,11 +303,11 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                             const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                             if (pass) {
                                 s.q[at] = make_float4(td.den, td.pu, td.qv, c0.w);
-                                s.qa[at] = make_uint2((uint32_t)lane, e);
+                                s.qa[at] = make_uint2((uint32_t)lane, __float_as_uint(c2.w));     // the candidate's triangle (r2.w)
                             }
                             qn += __popcll(m);
                             if (qn >= TR_DRAIN) {
-                                do tr_drain_full<true>(s, lane, qn, lrow4 + 3, 6, L); while (qn >= TR_DRAIN);
+                                do tr_drain_full<true>(s, lane, qn, geo4, 3, L); while (qn >= TR_DRAIN);
                                 occ = s.flag[lane] != 0u;                        // a lane found occluded stops walking
                             }
                         }
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
                         e++;
                         act = nact && !occ;
                     }
-                    if (qn) { tr_drain<true>(s, lane, qn, lrow4 + 3, 6, L); qn = 0; }
+                    if (qn) { tr_drain<true>(s, lane, qn, geo4, 3, L); qn = 0; }
                     if (s.flag[lane] != 0u) D = V3(0.0f, 0.0f, 0.0f);           // occluded (:313-314); any-hit is exact
                     result = add3(result, D);                      // (:319)
                     if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
         y1 += aa_step(rs);                                         // (:596)
     }
     count_tests(f, ntests);
+    count_candidates(f, ncand);
     if (!ok) return;
     avg = div3s(avg, (float)(rs * rs));                            // (:599)
     const size_t px = (size_t)y * f.W + x;

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define MIRT_API __attribute__((visibility("default")))
-#define MIRT_ABI_VERSION 1
+#define MIRT_ABI_VERSION 2
 #define MIRT_MAX_LIGHTS 32            /* Light lights[32], raytracer.cpp:48 / rasteriser.cpp:50 */
 
 typedef enum mirt_status {
@@ -78,6 +78,8 @@ typedef struct mirt_stats {
     float gpu_ms;                 /* hipEvent time of the call's device work; 0 unless profiling is on   */
     float kernel_ms[8];           /* per-kernel time of the call when profiling is on (see below)    */
     int32_t mode_used;            /* mirt_rt_mode actually used                                      */
+    uint64_t candidates;          /* ray-candidate pairs the frame's lists offered (>= tests: the binned kernel skips
+                                     candidates that cannot matter before it tests them); == tests elsewhere */
 } mirt_stats;
 
 /* indices into mirt_stats.kernel_ms */
