@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void k_bs_scatter(const uint32_t *__restrict__
 {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_wave[4];
+    if (*total_ptr > cap) return;                        // the list overflowed: this frame falls back (k_rt_brute_guard), nothing to sort
     uint32_t *s_base = s_dyn, *s_cnt = s_dyn + nbuckets;
     // bucket_base[b] = pairs in buckets < b: every workgroup scans the counts for itself; workgroup 0 publishes the result
     uint32_t carry = 0;
@@ -98,16 +99,18 @@ __global__ __launch_bounds__(256) void k_bs_scatter(const uint32_t *__restrict__
 
 // One workgroup per bucket of (1 << shift) <= 1024 bins.  Leaves bucket_cnt[bucket] = cursor[bucket] = 0 for the next sort.
 __global__ __launch_bounds__(256) void k_bs_local(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                  const uint32_t *__restrict__ total_ptr, uint32_t cap,
                                                   const uint32_t *__restrict__ bucket_base, uint32_t nbins, int shift,
                                                   uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ cursor,
                                                   uint32_t *__restrict__ bin_off, uint32_t *__restrict__ entries)
 {
     __shared__ uint32_t s_cnt[1024], s_wave[4];
     const uint32_t bucket = blockIdx.x;
+    if (threadIdx.x == 0) { bucket_cnt[bucket] = 0u; cursor[bucket] = 0u; }
+    if (*total_ptr > cap) return;                        // overflowed list (see k_bs_scatter): only the counters are reset
     const uint32_t beg = bucket_base[bucket], end = bucket_base[bucket + 1];
     const uint32_t nb = 1u << shift, mask = nb - 1u;
     for (uint32_t i = threadIdx.x; i < nb; i += 256) s_cnt[i] = 0u;
-    if (threadIdx.x == 0) { bucket_cnt[bucket] = 0u; cursor[bucket] = 0u; }
     __syncthreads();
     const bool small = end - beg <= 256u * BS_LOCAL_PER_THREAD;
     uint32_t lo[BS_LOCAL_PER_THREAD], v[BS_LOCAL_PER_THREAD], rank[BS_LOCAL_PER_THREAD];
@@ -179,8 +182,8 @@ hipError_t bucket_sort_pairs(const uint32_t *keys, const uint32_t *vals, const u
     const uint32_t wgs = std::min<uint32_t>(chunks, (uint32_t)cu_count * 2u);
     hipLaunchKernelGGL(k_bs_scatter, dim3(wgs), dim3(256), lds, stream, keys, vals, total_ptr, cap, nbuckets, shift, bucket_cnt, bucket_base,
                        cursor, tmp_keys, tmp_vals);
-    hipLaunchKernelGGL(k_bs_local, dim3(nbuckets), dim3(256), 0, stream, tmp_keys, tmp_vals, bucket_base, nbins, shift, bucket_cnt, cursor,
-                       bin_off, entries);
+    hipLaunchKernelGGL(k_bs_local, dim3(nbuckets), dim3(256), 0, stream, tmp_keys, tmp_vals, total_ptr, cap, bucket_base, nbins, shift, bucket_cnt,
+                       cursor, bin_off, entries);
     return hipGetLastError();
 }
 

@@ -47,8 +47,11 @@ struct RtTraceFrame {
     int tiles_x;
     int cube_bins;
     int cam_shells;
+    const uint32_t *pair_count;
+    uint32_t pair_cap;
 };
 template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
+__global__ void k_rt_brute_guard(const RtFrame, const uint32_t *, uint32_t);
 __global__ void k_geo_table(const float *, int, GeoRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *);
 size_t rt_trace_lds_bytes();
@@ -96,7 +99,16 @@ struct RtScratch {
     uint32_t *d_bucket = nullptr;                // bucket sort: counts | bases (+1) | cursors, cap_buckets each
     uint32_t cap_buckets = 0;
     bool bucket_dirty = false;                   // d_bucket may hold counts of a pass whose sort never ran
+    // sizing the pair list without a host sync: the count of a frame is copied to pinned memory behind it and looked at by a
+    // LATER frame of this stream; meanwhile the list is sized from the last count seen, with a device-side fallback if that
+    // was too small (k_rt_brute_guard)
+    uint32_t *h_count = nullptr;                 // pinned
+    hipEvent_t ev_count = nullptr;
+    bool count_pending = false;
+    bool have_known = false;
+    uint32_t known_pairs = 0;
     uint32_t cap_bins = 0, cap_entries = 0;
+    uint32_t cap_used = 0;                       // capacity the last binning pass told its kernels (== cap_entries outside tests)
     uint64_t bin_key = 0;
     uint32_t bin_entries = 0;                    // pairs of the current binning
     bool bin_key_valid = false;
@@ -390,9 +402,16 @@ int key_bits_for(uint32_t nbins)
 // count.  The list is sized from a count only the device knows: when `fresh` it is read back (4 bytes + one sync of this
 // stream) and the pass repeated if the list was too small; otherwise *npairs, the count of the identical pass before, holds.
 int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow *light_tab, uint32_t *counter, uint32_t *bin_off,
-             bool fresh, uint32_t *npairs)
+             bool fresh, uint32_t *npairs, bool may_guess = false)
 {
     int rc;
+    // a count an earlier frame left behind?
+    if (S.count_pending && hipEventQuery(S.ev_count) == hipSuccess) {
+        S.known_pairs = *S.h_count; S.have_known = true; S.count_pending = false;
+    }
+    (void)hipGetLastError();                                 // (hipErrorNotReady of the query is not an error)
+    static const bool always_sync = [] { const char *e = getenv("MIRT_BIN_SYNC"); return e && atoi(e) != 0; }();
+    const bool guess = fresh && may_guess && S.have_known && !always_sync;
     if (!S.d_entries || !S.cap_entries) {
         // first capacity of the pair list (grown on demand below); MIRT_BIN_INITIAL_PAIRS lets a test start small
         static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
@@ -401,7 +420,7 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     // workgroups striding over the (256-triangle chunk, frame) work items: 8 per CU (36 KiB of LDS each, 4 resident; 1 M
     // triangles at 8K: 4.06 -> 3.53 ms per frame against 3 per CU); MIRT_BIN_WGS overrides
     static const int bin_wgs = [] { const char *e = getenv("MIRT_BIN_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 16) ? v : 8; }();
-    static const int chunk_env = [] { const char *e = getenv("MIRT_BIN_CHUNK"); int v = e ? atoi(e) : 0; return (v == 64 || v == 256) ? v : 0; }();
+    static const int chunk_env = [] { const char *e = getenv("MIRT_BIN_CHUNK"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
     bs.chunk_tris = chunk_env ? chunk_env : 256;        // (64 measured slower on the 100 k soup: 86 vs 74 us for the whole binning, more flushes)
     const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + bs.chunk_tris - 1) / bs.chunk_tris) * bs.nframes, (long long)g.cu_count * bin_wgs));
     bs.counters = counter;
@@ -424,18 +443,44 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         bs.bucket_cnt = bcnt; bs.nbuckets = nbuckets; bs.bucket_shift = bucket_sort_shift(bs.nbins);
     }
     const size_t bin_lds = bucket_sort ? (size_t)nbuckets * sizeof(uint32_t) : 0;
+    if (guess) {
+        // room for half as many pairs again as the last frame seen produced; growing needs this stream idle (rare)
+        const size_t want = (size_t)S.known_pairs + S.known_pairs / 2 + 4096;
+        if (want > S.cap_entries) {
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            if ((rc = ensure_pairs(S, want + want / 4))) return rc;
+        }
+    }
     for (int attempt = 0; attempt < 2; attempt++) {
-        BinPairs pairs = { S.d_pair_keys, S.d_pair_vals, S.cap_entries };
-        bs.entries = S.d_entries; bs.cap_entries = S.cap_entries;
+        // MIRT_TEST_PAIR_CAP (tests only): a guessed list pretends to be this small, so that the overflow path runs
+        static const uint32_t test_cap = [] { const char *e = getenv("MIRT_TEST_PAIR_CAP"); long v = e ? atol(e) : 0; return v > 0 ? (uint32_t)v : 0u; }();
+        S.cap_used = (guess && test_cap && test_cap < S.cap_entries) ? test_cap : S.cap_entries;
+        BinPairs pairs = { S.d_pair_keys, S.d_pair_vals, S.cap_used };
+        bs.entries = S.d_entries; bs.cap_entries = S.cap_used;
         if (attempt) HIP_TRY(hipMemsetAsync(counter, 0, 4, g.stream));
         if (bucket_sort && (attempt || S.bucket_dirty)) HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (size_t)S.cap_buckets, g.stream));
         S.bucket_dirty = bucket_sort;                        // bucket counts pending until k_bs_local has consumed them
         hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(256), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
         if (!fresh) break;
+        if (guess) {
+            // no sync: the count travels to pinned memory behind the kernel and a later frame picks it up
+            if (!S.h_count) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.h_count), 64, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&S.ev_count, hipEventDisableTiming));
+            }
+            if (!S.count_pending) {
+                HIP_TRY(hipMemcpyAsync(S.h_count, counter, 4, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipEventRecord(S.ev_count, g.stream));
+                S.count_pending = true;
+            }
+            *npairs = S.known_pairs;
+            break;
+        }
         uint32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, counter, 4, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
         *npairs = total;
+        S.known_pairs = total; S.have_known = true;
         if (total <= S.cap_entries) break;
         if (attempt == 1) return fail(MIRT_ERR_HIP, "binning produced %u pairs twice with room for %u", total, S.cap_entries);
         if ((rc = ensure_pairs(S, (size_t)total + total / 8 + 4096))) return rc;
@@ -451,13 +496,13 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     }
 #endif
     if (bucket_sort) {
-        HIP_TRY(bucket_sort_pairs(S.d_pair_keys, S.d_pair_vals, counter, S.cap_entries, *npairs, bs.nbins, S.d_sorted_keys, S.d_tmp_vals,
+        HIP_TRY(bucket_sort_pairs(S.d_pair_keys, S.d_pair_vals, counter, S.cap_used, *npairs, bs.nbins, S.d_sorted_keys, S.d_tmp_vals,
                                   bcnt, bbase, bcur, bin_off, S.d_entries, g.cu_count, g.stream));
         S.bucket_dirty = false;                              // k_bs_local leaves the counts and cursors zero
         return MIRT_OK;
     }
     HIP_TRY(bin_sort_pairs(S.d_sort_temp, S.sort_temp_bytes, S.d_pair_keys, S.d_sorted_keys, S.d_pair_vals, S.d_entries, *npairs, key_bits_for(bs.nbins), g.stream));
-    hipLaunchKernelGGL(k_bin_offsets, dim3((bs.nbins + 1 + 255) / 256), dim3(256), 0, g.stream, S.d_sorted_keys, counter, S.cap_entries, bs.nbins, bin_off);
+    hipLaunchKernelGGL(k_bin_offsets, dim3((bs.nbins + 1 + 255) / 256), dim3(256), 0, g.stream, S.d_sorted_keys, counter, S.cap_used, bs.nbins, bin_off);
     return MIRT_OK;
 }
 
@@ -609,7 +654,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
                        (uint32_t *)nullptr, g.d_hits, S.d_bin_counters);
     // the pair count is read back (4 bytes + one sync of this stream) only when the inputs that determine it changed
     const bool fresh = !S.bin_key_valid || S.bin_key != key;
-    if ((rc = bin_pass(S, bs, S.d_cam_tab, nullptr, S.d_bin_counters, S.d_bin_off, fresh, &S.bin_entries))) return rc;
+    if ((rc = bin_pass(S, bs, S.d_cam_tab, nullptr, S.d_bin_counters, S.d_bin_off, fresh, &S.bin_entries, true))) return rc;
     S.bin_key = key;
     S.bin_key_valid = true;
     k_end(MIRT_K_BIN);
@@ -625,12 +670,24 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.tiles_x = bs.frame0.nbu;
     tf.cube_bins = cube_bins;
     tf.cam_shells = bs.frame0.nshell;
+    tf.pair_count = S.d_bin_counters;
+    tf.pair_cap = S.cap_used;
     const int tile_rows = bs.frame0.j1 - bs.frame0.j0;
     const size_t lds = rt_trace_lds_bytes();
     k_begin(MIRT_K_TRACE);
     const dim3 tgrid((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2);
     if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace<true>, tgrid, dim3(256), lds, g.stream, tf);
     else hipLaunchKernelGGL(k_rt_trace<false>, tgrid, dim3(256), lds, g.stream, tf);
+    {
+        // the safety net of a pair list sized without a read-back (bin_pass): leaves at once unless the list overflowed
+        RtFrame bf = f;
+        bf.cam_tab = S.d_cam_tab;
+        bf.light_tab = g.lc.d_light_tab;
+        bf.unsafe = nullptr;
+        const int rows = y1 - y0;
+        const size_t blds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
+        hipLaunchKernelGGL(k_rt_brute_guard, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), blds, g.stream, bf, S.d_bin_counters, S.cap_used);
+    }
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
@@ -1009,6 +1066,7 @@ extern "C" void mirt_shutdown(void)
         for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_bin_off,
                          (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp, (void *)S.d_tmp_vals, (void *)S.d_bucket })
             if (p) (void)hipFree(p);
+    for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }
     for (void *p : { (void *)g.d_geo, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
         if (p) (void)hipFree(p);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos,
@@ -1126,7 +1184,7 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     g.n = 0;
     if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
     if ((rc = dev_realloc(&g.d_culled, (size_t)2 * n))) return rc;
-    for (RtScratch &S : g.rt) S.bin_key_valid = false;      // the origin tables are re-sized by the next frame that needs them
+    for (RtScratch &S : g.rt) { S.bin_key_valid = false; S.have_known = false; S.count_pending = false; }   // tables and pair counts belong to the old scene
     HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
     for (int h = 0; h < 2; h++) {
         if (culled) HIP_TRY(hipMemcpy(g.d_culled + (size_t)h * n, culled, (size_t)n, hipMemcpyHostToDevice));

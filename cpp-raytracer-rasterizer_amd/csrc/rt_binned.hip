@@ -234,7 +234,18 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         __syncthreads();
     };
 
+#ifdef MIRT_BIN_STAMPS
+    long long st_setup = 0, st_prefix = 0, st_rounds = 0, st_huge = 0, st_flush = 0, st_t;
+    const long long st_begin = __builtin_amdgcn_s_memtime();
+    int st_nrounds = 0;
+#define STAMP(acc) { const long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - st_t; st_t = now_; }
+#else
+#define STAMP(acc)
+#endif
     for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
+#ifdef MIRT_BIN_STAMPS
+        st_t = __builtin_amdgcn_s_memtime();
+#endif
         const int chunk = w / bs.nframes, frame = w - chunk * bs.nframes;
         const uint32_t tri0 = (uint32_t)chunk * (uint32_t)chunk_tris, tri = tri0 + threadIdx.x;
         const BinFrameDesc fr = bs.frames ? bs.frames[frame] : bs.frame0;
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
 
 
 
+        STAMP(st_setup)
         // ---- direct items: constants to LDS, exclusive prefix of their box sizes over the workgroup ----
         const uint32_t ni = (uint32_t)(i_hi - i_lo + 1);
         const uint32_t nb = kind == 1 ? ni * (uint32_t)(j_hi - j_lo + 1) : 0u;
@@ -356,8 +368,12 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         if (threadIdx.x == 0) { atomicAdd(&bs.counters[8], T); atomicMax(&bs.counters[9], T); }
         { const unsigned long long md = __ballot(kind == 1); if (lane == 0) atomicAdd(&bs.counters[10], (uint32_t)__popcll(md)); }
 #endif
+        STAMP(st_prefix)
         // ---- flattened bin-by-bin tests: thread t of a round takes test t ----
         for (uint32_t r0 = 0; r0 < T; r0 += 256) {
+#ifdef MIRT_BIN_STAMPS
+            st_nrounds++;
+#endif
             __syncthreads();                          // s_pre written / the previous round's appends counted
             if (s_fill + 256u > (uint32_t)BIN_PAIR_BUF) flush();
             const uint32_t t = r0 + threadIdx.x;
@@ -397,6 +413,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
             }
         }
 
+        STAMP(st_rounds)
         // ---- huge items: the wave walks them one at a time, pairs into the same LDS buffer ----
         __syncthreads();                              // no flattened round (which counts on its 256 free slots) is still appending
         {
@@ -417,8 +434,18 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
                 bin_walk_large(u, utri, ushell, gr, lane, sink, ucells);
             }
         }
+        STAMP(st_huge)
     }
+#ifdef MIRT_BIN_STAMPS
+    st_t = __builtin_amdgcn_s_memtime();
+#endif
     flush();
+    STAMP(st_flush)
+#ifdef MIRT_BIN_STAMPS
+    if (threadIdx.x == 0 && (blockIdx.x % 97) == 0)
+        printf("wg %d: total %lld | setup %lld prefix %lld rounds %lld (%d) huge %lld flush %lld\n", (int)blockIdx.x, (long long)__builtin_amdgcn_s_memtime() - st_begin,
+               st_setup, st_prefix, st_rounds, st_nrounds, st_huge, st_flush);
+#endif
 }
 
 // bin_off[b] = first position of a key >= b in the sorted pair list (b = 0 .. nbins; bin_off[nbins] = total)

@@ -542,4 +542,16 @@ __global__ __launch_bounds__(256) void k_rt_brute(const RtFrame f)
 template __global__ void k_rt_brute<1>(const RtFrame);
 template __global__ void k_rt_brute<2>(const RtFrame);
 
+// The safety net of a binned frame whose pair list was sized from an EARLIER frame's count (no read-back, no host sync): when
+// this frame's binning produced more pairs than the list holds (*pair_count > pair_cap; the sort and k_rt_trace then do
+// nothing) the frame is rendered by brute force -- every ray against every triangle, same filter, same exact arithmetic, same
+// bits -- otherwise every workgroup leaves at once.  The host learns the count a frame later and grows the list.
+__global__ __launch_bounds__(256) void k_rt_brute_guard(const RtFrame f, const uint32_t *__restrict__ pair_count, uint32_t pair_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
+    if (__builtin_amdgcn_readfirstlane(*pair_count) <= pair_cap) return;
+    if (f.aa > 1) brute_body<2, true, true>(f, s_tab);
+    else brute_body<2, true, false>(f, s_tab);
+}
+
 }  // namespace mirt

@@ -158,6 +158,8 @@ struct RtTraceFrame {
     int tiles_x;                      // camera bins per row
     int cube_bins;                    // B: light-cube bins per face side
     int cam_shells;                   // depth shells per camera bin: bin b's list is cam_off[b * cam_shells] .. cam_off[(b + 1) * cam_shells]
+    const uint32_t *pair_count;       // pairs this frame's binning produced / room in the pair list: beyond it the lists are
+    uint32_t pair_cap;                // incomplete, the kernel does nothing and k_rt_brute_guard renders the frame
 };
 
 template <bool AA>
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
     const bool tile_ok = tx < tf.tiles_x && ty * BIN_TILE < f.y1;
     const bool ok = tile_ok && x < f.W && y >= f.y0 && y < f.y1;
     if (!tile_ok) return;                                  // wave-uniform
+    if (__builtin_amdgcn_readfirstlane(*tf.pair_count) > tf.pair_cap) return;
     const v3 cam = ld3(f.cam);
     const int rs = AA ? f.aa : 1;                          // realSamples (:549-554); compile-time 1 without supersampling
 
