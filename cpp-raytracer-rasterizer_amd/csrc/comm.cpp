@@ -211,4 +211,31 @@ bool comm_gather_bands(Comm *c, int root, const GatherPiece *pieces, int npieces
     return true;
 }
 
+bool comm_selfcheck(Comm *c, size_t bytes, hipStream_t stream)
+{
+    if (!bytes) return true;
+    std::vector<unsigned char> pattern(bytes), back(bytes);
+    for (size_t i = 0; i < bytes; i++) pattern[i] = (unsigned char)((i * 2654435761u) >> 13);
+    void *src = nullptr, *dst = nullptr;
+    bool ok = hipMalloc(&src, bytes) == hipSuccess && hipMalloc(&dst, bytes) == hipSuccess &&
+              hipMemcpy(src, pattern.data(), bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dst, 0, bytes) == hipSuccess;
+    if (!ok) c->err = "link check: device buffers";
+    if (ok && c->shm) ok = shm_send(c, src, bytes, c->rank, stream) && shm_recv(c, dst, bytes, c->rank, stream);
+    else if (ok) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.Send(src, bytes, ncclUint8, c->rank, c->nccl, stream);
+        if (r == ncclSuccess) r = g_rccl.Recv(dst, bytes, ncclUint8, c->rank, c->nccl, stream);
+        const ncclResult_t e = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) { c->err = std::string("link check: ") + g_rccl.GetErrorString(r); ok = false; }
+    }
+    if (ok && (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(back.data(), dst, bytes, hipMemcpyDeviceToHost) != hipSuccess)) {
+        c->err = "link check: reading the received bytes back failed";
+        ok = false;
+    }
+    if (ok && memcmp(back.data(), pattern.data(), bytes) != 0) { c->err = "link check: received bytes differ from the bytes sent"; ok = false; }
+    (void)hipFree(src); (void)hipFree(dst);
+    return ok;
+}
+
 }  // namespace mirt

@@ -31,4 +31,8 @@ struct GatherPiece { void *ptr; size_t bytes; int peer; };
 // All pieces in one group on `stream` (RCCL: asynchronous, stream-ordered; shm: synchronous).
 bool comm_gather_bands(Comm *c, int root, const GatherPiece *pieces, int npieces, hipStream_t stream);
 
+// Link check: `bytes` of a pattern travel from this rank to ITSELF through the group's transport (one send + one receive in a
+// group, as in a gather) and are compared.  Works with any world size, so it also covers the transport on a one-GPU box.
+bool comm_selfcheck(Comm *c, size_t bytes, hipStream_t stream);
+
 }  // namespace mirt

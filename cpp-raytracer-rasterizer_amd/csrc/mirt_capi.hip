@@ -1529,6 +1529,16 @@ extern "C" int mirt_comm_init(const void *id128, int rank, int world)
     return MIRT_OK;
 }
 
+extern "C" int mirt_comm_selfcheck(size_t bytes)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!g.comm) return fail(MIRT_ERR_INVALID_ARGUMENT, "mirt_comm_selfcheck before mirt_comm_init");
+    HIP_TRY(sync_all());
+    if (!comm_selfcheck(g.comm, bytes, g.comm_stream)) return fail(MIRT_ERR_HIP, "%s", comm_error(g.comm));
+    return MIRT_OK;
+}
+
 extern "C" int mirt_comm_shutdown(void)
 {
     if (!g.init || !g.comm) return MIRT_OK;

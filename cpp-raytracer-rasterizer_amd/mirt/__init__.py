@@ -22,7 +22,7 @@ EXPORTS = (
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
     "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats", "mirt_surface_register", "mirt_surface_unregister",
-    "mirt_band_of", "mirt_band_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
+    "mirt_band_of", "mirt_band_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_comm_selfcheck", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
 )
 
 
@@ -87,6 +87,7 @@ def load():
     lib.mirt_band_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]
     lib.mirt_comm_create_id.argtypes = [_vp]
     lib.mirt_comm_init.argtypes = [_vp, C.c_int, C.c_int]
+    lib.mirt_comm_selfcheck.argtypes = [C.c_size_t]
     lib.mirt_raytrace_sharded.argtypes = [C.POINTER(View), C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int]
     lib.mirt_rasterise_sharded.argtypes = [C.POINTER(View), C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int]
     _lib = lib
@@ -383,6 +384,10 @@ def comm_init(comm_id, rank, world):
 
 def comm_shutdown():
     _check(load().mirt_comm_shutdown())
+
+
+def comm_selfcheck(nbytes):
+    _check(load().mirt_comm_selfcheck(C.c_size_t(int(nbytes))))
 
 
 def view_array(views):

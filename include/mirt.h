@@ -257,6 +257,9 @@ MIRT_API int mirt_band_plan(int world, int root, int width, int height, int nvie
 MIRT_API int mirt_comm_create_id(void *id128);
 MIRT_API int mirt_comm_init(const void *id128, int rank, int world);
 MIRT_API int mirt_comm_shutdown(void);
+/* Link check after mirt_comm_init: `bytes` of a pattern travel from this rank to itself through the group's transport (one send
+ * and one receive in a group, exactly as in a gather) and are compared.  Any world size; synchronous. */
+MIRT_API int mirt_comm_selfcheck(size_t bytes);
 MIRT_API int mirt_raytrace_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,
                                    int mode, int root, void *d_frames, int pitch_bytes);
 MIRT_API int mirt_rasterise_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,

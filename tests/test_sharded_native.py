@@ -4,7 +4,9 @@ Without a GPU: the band partition against mirt/sharding.py's, the gather plan ap
 ragged frames, and a C++ program that runs the plan with one process per rank (world sizes 2, 3, 5) over pipes.
 -m gpu: two and three real processes on device 0 exchange their bands through the library's host-staged loopback transport
 (MIRT_COMM=shm; RCCL needs one GPU per rank, which the driver's 8-GPU run provides) and the root's frames must equal
-single-GPU frames byte for byte -- ray tracer (tile and binned kernels) and rasteriser, several frames per gather.
+single-GPU frames byte for byte -- ray tracer (tile and binned kernels) and rasteriser, several frames per gather.  What one
+GPU CAN run of the RCCL transport: a group of one rank -- the library is loaded (beside PyTorch's copy too), the communicator
+created, a grouped ncclSend + ncclRecv to the rank itself compared byte for byte (mirt_comm_selfcheck), a sharded call made.
 """
 import os
 import subprocess
@@ -131,3 +133,44 @@ def test_sharded_frames_through_the_loopback_transport(tmp_path, world, root):
             raise
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+SELF_CODE = r"""
+import os, sys, numpy as np
+sys.path[:0] = [%(pkg)r, %(tests)r]
+if sys.argv[1] == "torch":
+    import torch                              # the process then already holds PyTorch's librccl: the library must reuse it
+    torch.zeros(4, device="cuda:0").sum().item()
+import mirt
+from devbuf import DeviceArray
+mirt.init(0)
+mirt.comm_init(mirt.comm_create_id(), 0, 1)
+for nbytes in (1, 4096, 8 << 20):
+    mirt.comm_selfcheck(nbytes)
+tris = mirt.scene_cornell()
+mirt.scene_upload(tris)
+W, H = 160, 90
+views = [mirt.make_view((0.05 * i, 0, -2.6), mirt.rot_from_yaw(0.1 * i, 1.0), 70.0, W, H) for i in range(2)]
+L = np.array([[0.0, -0.5, -0.7, 1, 1, 1, 14]], np.float32)
+frames = DeviceArray((2, H, W), np.uint32, 0x33)
+mirt.set_frames_in_flight(1)
+mirt.prepared_sharded("rt", views, L, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, frames.ptr, W * 4)()
+mirt.sync()
+got = frames.read()
+for i, v in enumerate(views):
+    ref = DeviceArray((H, W), np.uint32, 0x33)
+    mirt.raytrace_device(v, L, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, ref.ptr, W * 4)
+    assert np.array_equal(got[i], ref.read())
+mirt.comm_shutdown()
+mirt.shutdown()
+print("selfcheck ok", flush=True)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host", ["plain", "torch"])
+def test_rccl_group_of_one_rank(host):
+    code = SELF_CODE % {"pkg": os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), "tests": os.path.join(ROOT, "tests")}
+    env = {k: v for k, v in os.environ.items() if k != "MIRT_COMM"}
+    r = subprocess.run([sys.executable, "-c", code, host], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "selfcheck ok" in r.stdout, r.stdout + r.stderr
