@@ -118,7 +118,9 @@ struct RtScratch {
 // so they are built once per (scene version, light positions, grid) and shared by the frames of both streams.
 struct LightCache {
     bool valid = false;
-    uint64_t key = 0;
+    uint64_t key = 0;                            // scene version + light positions (not the grid)
+    int cube_bins = 0;                           // bins per face side of the tables held
+    int stable = 0;                              // consecutive frames that found their lights in the cache
     OriginRow *d_light_tab = nullptr;            // nl x n origin rows
     size_t cap_tab = 0;
     BinFrameDesc *d_frames = nullptr;            // 6 x nl frame descriptors
@@ -508,16 +510,28 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
 
 // The light-cube bins (six faces of B x B bins around every light position) and their expanded rows.  Built on g.stream as a
 // barrier call -- the frames of both streams read the tables -- whenever the scene, a light position or the grid changed.
-int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int nlights, int cube_bins)
+// Grid: the fine grid (`fine_bins` per face side) shortens the shadow lists but costs ~1 ms to build for 100 k triangles, the
+// coarse one (CUBE_BINS_MIN) a third of that.  The reference moves the light with keys (raytracer.cpp:152-162) as readily as the
+// camera, so lights that changed since the previous frame get the coarse grid, and the fine one is built once the same lights have
+// been seen for LIGHT_STABLE_FRAMES frames in a row (`adapt` false: always `fine_bins`).  The grid never changes a result.
+constexpr int LIGHT_STABLE_FRAMES = 4;
+int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int nlights, int fine_bins, bool adapt)
 {
     int rc;
     LightCache &C = g.lc;
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
     {
         auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
-        mix(origins + 3, sizeof(float) * 3 * nlights); mix(&nlights, 4); mix(&g.n, 4); mix(&cube_bins, 4);
+        mix(origins + 3, sizeof(float) * 3 * nlights); mix(&nlights, 4); mix(&g.n, 4);
     }
-    if (C.valid && C.key == key) return MIRT_OK;
+    int cube_bins = fine_bins;
+    if (C.valid && C.key == key) {
+        C.stable++;
+        if (C.cube_bins == fine_bins || (adapt && C.stable < LIGHT_STABLE_FRAMES)) return MIRT_OK;      // keep the tables held
+    } else {
+        C.stable = 0;
+        if (adapt) cube_bins = std::min(fine_bins, CUBE_BINS_MIN);
+    }
     C.valid = false;
     const int other = (g.stream == g.streams[0]) ? 1 : 0;
     if (g.in_flight == 2) {                                  // frames of the other stream may still read the old tables
@@ -589,6 +603,7 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
         HIP_TRY(hipStreamWaitEvent(g.streams[other], g.ev_cull, 0));
     }
     C.key = key;
+    C.cube_bins = cube_bins;
     C.valid = true;
     return MIRT_OK;
 }
@@ -599,15 +614,17 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     int rc;
     g.stats.mode_used = MIRT_RT_BINNED;
     // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists; the bins are built once per (scene,
-    // lights), not per frame, so what they cost is memory (96 bytes per (bin, triangle) pair) and the build when a light
-    // moves.  Measured on the 100 k soup at 1080p (trace kernel): 64: 153 us, 128: 125 us, 256: 105 us.  MIRT_CUBE_BINS=64|128|256
-    // overrides.
+    // lights), not per frame, so what they cost is memory (48 bytes per (bin, triangle) pair) and the build when a light
+    // moves (light_cache_ensure picks the coarse grid for lights that just moved).  Measured on the 100 k soup at 1080p (trace
+    // kernel): 64: 153 us, 128: 125 us, 256: 105 us.  MIRT_CUBE_BINS=64|128|256 fixes the grid.
     static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
-    int cube_bins = g.n < 2000 ? CUBE_BINS_MIN : (g.n < 20000 ? 2 * CUBE_BINS_MIN : 4 * CUBE_BINS_MIN);
-    if (cube_override == 64 || cube_override == 128 || cube_override == 256) cube_bins = cube_override;
+    int fine_bins = g.n < 2000 ? CUBE_BINS_MIN : (g.n < 20000 ? 2 * CUBE_BINS_MIN : 4 * CUBE_BINS_MIN);
+    const bool fixed_grid = cube_override == 64 || cube_override == 128 || cube_override == 256;
+    if (fixed_grid) fine_bins = cube_override;
 
     k_begin(MIRT_K_BIN);
-    if ((rc = light_cache_ensure(S, f, origins, nlights, cube_bins))) return rc;
+    if ((rc = light_cache_ensure(S, f, origins, nlights, fine_bins, !fixed_grid))) return rc;
+    const int cube_bins = g.lc.cube_bins;
 
     BinSet bs;
     memset(&bs, 0, sizeof bs);

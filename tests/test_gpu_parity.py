@@ -413,6 +413,33 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_rt_binned_light_cube_follows_a_moving_light():
+    """Lights that moved since the previous frame get the coarse light cube, the fine one (256 bins per side from 20 k
+    triangles) is built once the lights have stood still for four frames; neither changes a result.  Frames with a fixed
+    light (coarse x 4, then fine), then a light that moves every frame: every one == brute force bit for bit, and the
+    executed shadow tests drop when the fine grid takes over."""
+    tris = mirt.scene_soup(21, 24000, 0.06)
+    rot = np.zeros(9, np.float32); rot[0] = rot[4] = rot[8] = 1
+    view = mirt.make_view((0.0, 0.0, -1.6), rot, 150.0, 300, 180)
+    mirt.scene_upload(tris)
+
+    def both(lights):
+        a = mirt.raytrace(view, lights, mode=mirt.RT_BRUTE)
+        b = mirt.raytrace(view, lights, mode=mirt.RT_BINNED)
+        assert b["stats"]["mode_used"] == mirt.RT_BINNED
+        assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+        assert np.array_equal(a["xrgb"], b["xrgb"])
+        return b["stats"]["tests"]
+
+    fixed = np.array([[0.1, -0.4, -0.6, 1, 1, 1, 14]], np.float32)
+    tests = [both(fixed) for _ in range(7)]
+    assert max(tests[4:]) < min(tests[:4]), tests         # (the count varies a little from run to run: early exits race)
+    for i in range(4):
+        moving = fixed.copy(); moving[0, 0] += 0.05 * (i + 1)
+        both(moving)
+    assert both(fixed) > max(tests[4:])                 # back on the first position: moved again, so the coarse grid
+
+
 # ---- edge cases: tiny / ragged frames and kernel-selection boundaries ----------------------------------
 
 @pytest.mark.parametrize("W,H", [(1, 1), (2, 3), (3, 3), (7, 5), (65, 9), (130, 3)])

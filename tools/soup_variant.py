@@ -20,11 +20,11 @@ x = DeviceArray((H, W), np.uint32)
 mirt.set_profiling(True)
 for lights, tag in ((LIGHT, "1 light"), (np.zeros((0, 7), np.float32), "no light")):
     acc = {}
-    for it in range(12):
+    for it in range(16):
         mirt.raytrace_device(view, lights, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, x.ptr, W * 4)
         mirt.sync()
         st = mirt.stats()
-        if it >= 2:
+        if it >= 6:
             for k, v in st["kernel_ms"].items():
                 acc[k] = acc.get(k, 0.0) + v / 10
     print("%-9s kernel_ms %s tests %d" % (tag, {k: round(v, 4) for k, v in acc.items() if v}, st["tests"]))
