@@ -430,6 +430,11 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
             out["static_camera"] = static
         if host:
             out["host_path"] = host
+            # frames/s INCLUDING the framebuffer's way to the host surface; synchronous Draw() and the
+            # present-one-draw-the-next loop (mirt_*_async)
+            out["frames_per_s_host"] = host.get("frames_per_s")
+            if "frames_per_s" in host.get("async", {}):
+                out["frames_per_s_host_async"] = host["async"]["frames_per_s"]
         px = W * H
         if kind == "rt":
             out.update({
@@ -549,6 +554,27 @@ def host_path_rate(mirt, kind, views, mode, W, H, t_frame):
         mirt.surface_unregister(surf)
     except mirt.MirtError as e:
         out["registered"] = {"error": str(e)}
+    # asynchronous frames (mirt_*_async): two registered surfaces in turn, two frames in flight, ONE sync at the end -- the loop
+    # that presents one surface while the next is drawn; the copy of frame i overlaps the render of frame i + 1
+    try:
+        pair = np.zeros((2, H, W), np.uint32)
+        mirt.surface_register(pair)
+        was = 2                                             # the timed loop ran with two frames in flight; left that way below
+        mirt.set_frames_in_flight(2)
+        calls = [mirt.prepared_async(kind, v, LIGHT, INDIRECT, mode, pair[i & 1]) for i, v in enumerate(views[:16])]
+        for i in range(4):
+            calls[i % len(calls)]()
+        mirt.sync()
+        t0 = time.perf_counter()
+        for i in range(n):
+            calls[i % len(calls)]()
+        mirt.sync()
+        adt = (time.perf_counter() - t0) / n
+        out["async"] = {"frames_per_s": round(1.0 / adt, 2), "ms_per_frame": round(adt * 1e3, 4), "surface_GB_per_s": round(W * H * 4 / adt / 1e9, 2),
+                        "link_frac": round(W * H * 4 / adt / 1e9 / 63.0, 3), "frames_in_flight": was}
+        mirt.surface_unregister(pair)
+    except mirt.MirtError as e:
+        out["async"] = {"error": str(e)}
     # the floor: a bare device-to-host copy of the same surface into pinned memory (no render), same sync per frame
     try:
         import torch
@@ -568,10 +594,14 @@ def host_path_rate(mirt, kind, views, mode, W, H, t_frame):
     best = min((out[k] for k in ("pageable", "registered") if "ms_per_frame" in out.get(k, {})), key=lambda r: r["ms_per_frame"])
     if "ms_per_frame" in out["bare_pinned_copy"]:
         out["copy_floor_frac"] = round(out["bare_pinned_copy"]["ms_per_frame"] / best["ms_per_frame"], 3)
+        if "ms_per_frame" in out.get("async", {}):
+            out["async"]["copy_floor_frac"] = round(out["bare_pinned_copy"]["ms_per_frame"] / out["async"]["ms_per_frame"], 3)
     out.update({"frames_per_s": best["frames_per_s"], "ms_per_frame": best["ms_per_frame"],
                 "note": "mirt_raytrace / mirt_rasterise into a host surface (the SDL surface of the reference): render + delivery, "
                         "synchronous per frame; registered = mirt_surface_register'ed surface; PCIe Gen5 x16 is 63 GB/s (link_frac); "
-                        "bare_pinned_copy = the same bytes copied device-to-host with no render at all, copy_floor_frac = that floor / our frame"})
+                        "bare_pinned_copy = the same bytes copied device-to-host with no render at all, copy_floor_frac = that floor / our frame; "
+                        "async = mirt_*_async into two registered surfaces in turn, two frames in flight, one sync at the end (the copy of a "
+                        "frame overlaps the render of the next)"})
     return out
 
 

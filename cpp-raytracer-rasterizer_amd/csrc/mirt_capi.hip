@@ -186,6 +186,11 @@ struct Ctx {
     // staging for the host-buffer entry points
     void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr, *d_pos = nullptr;
     size_t cap_px = 0;
+    // ... and for the asynchronous ones: two XRGB planes used in turn (frame i + 2 runs on the stream of frame i, or behind a
+    // barrier call, so it is ordered after the copy that reads frame i's plane)
+    void *d_async[2] = { nullptr, nullptr };
+    size_t async_cap_px = 0;
+    unsigned async_no = 0;
     RasterScratch raster[2];                     // one set of rasteriser scratch per stream (frames in flight)
 
     // several GPUs: this process's place among the ranks that shard a frame, and its band buffers (two: the gather of one
@@ -1086,7 +1091,7 @@ extern "C" void mirt_shutdown(void)
     for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }
     for (void *p : { (void *)g.d_geo, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
         if (p) (void)hipFree(p);
-    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos,
+    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos, g.d_async[0], g.d_async[1],
                      (void *)g.dof[0].rgb, (void *)g.dof[0].fd, (void *)g.dof[0].xrgb, (void *)g.dof[0].index, (void *)g.dof[0].zinv,
                      (void *)g.dof[1].rgb, (void *)g.dof[1].fd, (void *)g.dof[1].xrgb, (void *)g.dof[1].index, (void *)g.dof[1].zinv })
         if (p) (void)hipFree(p);
@@ -1368,6 +1373,51 @@ extern "C" int mirt_raytrace_ex(const mirt_view *view, const mirt_light *lights,
     return MIRT_OK;
 }
 
+// ---- asynchronous delivery into a registered host surface --------------------------------------------------------------
+// Render into one of two library-owned planes, then ONE stream-ordered DMA copy into the pinned surface; no host sync.  With
+// two frames in flight the copy of frame i (the DMA engine) runs while frame i + 1 renders, so a loop that presents one
+// surface while the next one is drawn moves frames at the rate of the link alone.
+static int async_plane(size_t px, void **plane)
+{
+    if (px > g.async_cap_px) {
+        HIP_TRY(sync_all());                                 // frames in flight may still read the planes
+        for (void *&p : g.d_async) { if (p) (void)hipFree(p); p = nullptr; }
+        g.async_cap_px = 0;
+        for (void *&p : g.d_async)
+            if (hipMalloc(&p, px * 4) != hipSuccess) { p = nullptr; return fail(MIRT_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) for an asynchronous frame", px * 4); }
+        g.async_cap_px = px;
+    }
+    *plane = g.d_async[g.async_no++ & 1];
+    return MIRT_OK;
+}
+
+static int async_target(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect, uint32_t *out_xrgb, int pitch_bytes, char **alias)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if ((rc = check_view(view, lights, nlights, indirect))) return rc;
+    if (!out_xrgb) return fail(MIRT_ERR_INVALID_ARGUMENT, "out_xrgb must not be NULL");
+    if (pitch_bytes < view->width * 4 || (pitch_bytes & 3)) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, view->width);
+    *alias = registered_alias(out_xrgb, (size_t)pitch_bytes, view->height);
+    if (!*alias) return fail(MIRT_ERR_INVALID_ARGUMENT, "an asynchronous frame needs a surface registered with mirt_surface_register (pageable memory cannot take a stream-ordered copy)");
+    return MIRT_OK;
+}
+
+extern "C" int mirt_raytrace_async(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                   int mode, uint32_t *out_xrgb, int pitch_bytes)
+{
+    int rc;
+    char *alias = nullptr;
+    if ((rc = async_target(view, lights, nlights, indirect, out_xrgb, pitch_bytes, &alias))) return rc;
+    const int W = view->width, H = view->height;
+    if (host_direct())
+        return mirt_raytrace_device_ex(view, lights, nlights, indirect, mode, 0, H, 0, alias, pitch_bytes, nullptr, nullptr, nullptr, nullptr);
+    void *plane = nullptr;
+    if ((rc = async_plane((size_t)W * H, &plane))) return rc;
+    if ((rc = mirt_raytrace_device_ex(view, lights, nlights, indirect, mode, 0, H, 0, plane, W * 4, nullptr, nullptr, nullptr, nullptr))) return rc;
+    return copy_plane_interior(out_xrgb, pitch_bytes, plane, W * 4, W, H);      // on the stream the frame was queued on
+}
+
 // ---- rasteriser -------------------------------------------------------------------------------------
 
 static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
@@ -1455,6 +1505,23 @@ extern "C" int mirt_rasterise(const mirt_view *view, const mirt_light *lights, i
     if (out_zinv) HIP_TRY(hipMemcpyAsync(out_zinv, g.d_zinv, px * 4, hipMemcpyDeviceToHost, g.stream));
     if (out_index) HIP_TRY(hipMemcpyAsync(out_index, g.d_index, px * 4, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_rasterise_async(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                    uint32_t *out_xrgb, int pitch_bytes)
+{
+    int rc;
+    char *alias = nullptr;
+    if ((rc = async_target(view, lights, nlights, indirect, out_xrgb, pitch_bytes, &alias))) return rc;
+    const int W = view->width, H = view->height;
+    if (host_direct())
+        return mirt_rasterise_device(view, lights, nlights, indirect, 0, H, 0, alias, pitch_bytes, nullptr, nullptr, nullptr);
+    void *plane = nullptr;
+    if ((rc = async_plane((size_t)W * H, &plane))) return rc;
+    if ((rc = mirt_rasterise_device(view, lights, nlights, indirect, 0, H, 0, plane, W * 4, nullptr, nullptr, nullptr))) return rc;
+    // the rasteriser's Update() paints the whole surface (rasteriser.cpp:190): every word is written
+    HIP_TRY(hipMemcpy2DAsync(out_xrgb, pitch_bytes, plane, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, g.stream));
     return MIRT_OK;
 }
 

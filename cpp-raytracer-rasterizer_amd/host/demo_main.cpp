@@ -1,7 +1,8 @@
 // demo_main.cpp -- the reference's main() loops (raytracer.cpp:113-178, rasteriser.cpp:101-149) on top of
 // mirt_draw.hpp, without SDL: a heap surface stands in for the window, one Update()+Draw() per "loop".
-//   demo_main rt|rtsoft|rtaa|rtdof|raster|rasterdof|rasterstl [width height [out.bmp [out.xrgb [model.stl]]]]
-//   (rtsoft: SOFT_SHADOWS_ENABLED, rtaa: AA_ENABLED, *dof: DOF_ENABLED, rasterstl: the CUSTOM_MODEL build, culled on the GPU)
+//   demo_main rt|rtsoft|rtaa|rtdof|rtasync|raster|rasterdof|rasterstl|rasterasync [width height [out.bmp [out.xrgb [model.stl]]]]
+//   (rtsoft: SOFT_SHADOWS_ENABLED, rtaa: AA_ENABLED, *dof: DOF_ENABLED, rasterstl: the CUSTOM_MODEL build, culled on the GPU,
+//   *async: DrawAsync() into two registered surfaces in turn with two frames in flight, Present() before the screenshot)
 // Writes a BMP screenshot (what SDL_SaveBMP(screen, "screenshot.bmp") does at :175/:147) and, optionally, the
 // raw XRGB words so tests can compare them with the oracle.
 #include "mirt_draw.hpp"
@@ -18,9 +19,26 @@ int main(int argc, char **argv)
     const char *bmp = argc > 4 ? argv[4] : "screenshot.bmp";
     const char *raw = argc > 5 ? argv[5] : nullptr;
     try {
-        std::vector<uint32_t> pixels((size_t)W * H, 0u);
+        std::vector<uint32_t> pixels((size_t)W * H, 0u), back((size_t)W * H, 0u);
         Surface screen = { pixels.data(), W, H, W * 4 };            // InitializeSDL(W, H): 32-bit SWSURFACE
-        if (which == "rt" || which == "rtsoft" || which == "rtaa" || which == "rtdof") {
+        Surface second = { back.data(), W, H, W * 4 };              // *async: the surface being drawn while `screen` is shown
+        const bool async = which == "rtasync" || which == "rasterasync";
+        // the loop of the *async modes: eight frames with the camera turning back to where it started, surfaces in turn, so
+        // that the last frame -- the reference view -- lands in `screen`
+        auto async_loop = [&](auto &app) {
+            check(mirt_surface_register(screen.pixels, (size_t)H * screen.pitch), "mirt_surface_register");
+            check(mirt_surface_register(second.pixels, (size_t)H * second.pitch), "mirt_surface_register");
+            check(mirt_set_frames_in_flight(2), "mirt_set_frames_in_flight");
+            for (int loop = 0; loop < 8; loop++) {
+                app.yaw = 0.05f * (float)(7 - loop);
+                app.Update();
+                app.DrawAsync((loop & 1) ? screen : second);
+            }
+            app.Present();
+            check(mirt_surface_unregister(second.pixels), "mirt_surface_unregister");
+            check(mirt_surface_unregister(screen.pixels), "mirt_surface_unregister");
+        };
+        if (which == "rt" || which == "rtsoft" || which == "rtaa" || which == "rtdof" || which == "rtasync") {
             RayTracer app;
             app.SOFT_SHADOWS_ENABLED = which == "rtsoft";
             app.AA_ENABLED = which == "rtaa";
@@ -34,7 +52,8 @@ int main(int argc, char **argv)
             check(mirt_set_profiling(1), "mirt_set_profiling");       // "Render time" below is the GPU time of the call
             app.LoadTestModel();                                     // :149
             app.cameraRot[1][1] = 1.0f;                              // :162
-            for (int loop = 0; loop < 2; loop++) {                   // while (NoQuitMessageSDL())
+            if (async) async_loop(app);
+            else for (int loop = 0; loop < 2; loop++) {              // while (NoQuitMessageSDL())
                 app.Update();
                 if (app.isUpdated) { app.Draw(); app.isUpdated = false; }
             }
@@ -55,7 +74,8 @@ int main(int argc, char **argv)
                 app.LoadTestModel();                                 // :112
             }
             app.cameraRot[1][1] = 1.01f;                             // :115 (sic)
-            for (int loop = 0; loop < 2; loop++) {
+            if (async) async_loop(app);
+            else for (int loop = 0; loop < 2; loop++) {
                 app.Update();
                 if (app.isUpdated) { app.Draw(); app.isUpdated = false; }
             }

@@ -121,19 +121,35 @@ struct RayTracer {
     // the 1-pixel border is left as it was (raytracer.cpp:618-620).
     void Draw()
     {
+        const mirt_view view = marshal();
+        check(mirt_raytrace(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLight.x,
+                            MIRT_RT_AUTO, screen.pixels, screen.pitch, nullptr, nullptr), "mirt_raytrace");
+    }
+    // Draw() for a loop that presents one surface while the next one is drawn: the frame is queued into `target` (inside
+    // a surface registered with mirt_surface_register) and the call returns; Present() is the loop's SDL_UpdateRect (:653).
+    // With mirt_set_frames_in_flight(2) and two surfaces used in turn, frame i travels to the host while frame i + 1 renders.
+    void DrawAsync(const Surface &target)
+    {
+        const mirt_view view = marshal();
+        check(mirt_raytrace_async(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLight.x,
+                                  MIRT_RT_AUTO, target.pixels, target.pitch), "mirt_raytrace_async");
+    }
+    static void Present() { check(mirt_sync(), "mirt_sync"); }
+
+private:
+    mirt_view marshal()                                            // the globals -> the POD arguments of mirt.h
+    {
         if (scene_dirty) {
             check(mirt_scene_upload(&triangles[0].v0.x, nullptr, (int)triangles.size()), "mirt_scene_upload");
             scene_dirty = false;
         }
-        const mirt_view view = make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
         check(mirt_set_antialiasing(AA_ENABLED ? AA_SAMPLES : 1), "mirt_set_antialiasing");   // realSamples (:549-554)
         if (SOFT_SHADOWS_ENABLED)                                  // DirectLight's `samples` (:272-275)
             check(mirt_set_soft_shadows(SOFT_SHADOWS_SAMPLES, &randomPositions[0].x, NUM_LIGHTS * SOFT_SHADOWS_SAMPLES), "mirt_set_soft_shadows");
         else
             check(mirt_set_soft_shadows(1, nullptr, 0), "mirt_set_soft_shadows");
         check(mirt_set_depth_of_field(DOF_ENABLED ? DOF_KERNEL_SIZE : 0, FOCAL_LENGTH), "mirt_set_depth_of_field");   // CalculateDOF (:608-646)
-        check(mirt_raytrace(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLight.x,
-                            MIRT_RT_AUTO, screen.pixels, screen.pitch, nullptr, nullptr), "mirt_raytrace");
+        return make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
     }
 };
 
@@ -208,16 +224,30 @@ struct Rasteriser {
     }
     void Draw()
     {
+        const mirt_view view = marshal();
+        check(mirt_rasterise(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLightPowerPerArea.x,
+                             screen.pixels, screen.pitch, nullptr, nullptr, nullptr), "mirt_rasterise");
+    }
+    // see RayTracer::DrawAsync (Present() is the SDL_UpdateRect of rasteriser.cpp:528)
+    void DrawAsync(const Surface &target)
+    {
+        const mirt_view view = marshal();
+        check(mirt_rasterise_async(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLightPowerPerArea.x,
+                                   target.pixels, target.pitch), "mirt_rasterise_async");
+    }
+    static void Present() { check(mirt_sync(), "mirt_sync"); }
+
+private:
+    mirt_view marshal()
+    {
         if (scene_dirty) {
             check(mirt_scene_upload(packed.data(), culled.data(), (int)triangles.size()), "mirt_scene_upload");
             scene_dirty = false;
         } else if (!GPU_CULL) {                       // with GPU_CULL the flags are already on the device
             check(mirt_scene_set_culled(culled.data(), (int)culled.size()), "mirt_scene_set_culled");
         }
-        const mirt_view view = make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
         check(mirt_set_depth_of_field(DOF_ENABLED ? DOF_KERNEL_SIZE : 0, FOCAL_LENGTH), "mirt_set_depth_of_field");   // CalculateDOF (:484-529)
-        check(mirt_rasterise(&view, reinterpret_cast<const mirt_light *>(lights), NUM_LIGHTS, &indirectLightPowerPerArea.x,
-                             screen.pixels, screen.pitch, nullptr, nullptr, nullptr), "mirt_rasterise");
+        return make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);
     }
 };
 

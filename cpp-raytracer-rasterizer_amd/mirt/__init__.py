@@ -21,7 +21,7 @@ EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
     "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
-    "mirt_rasterise_device", "mirt_get_stats", "mirt_surface_register", "mirt_surface_unregister",
+    "mirt_rasterise_device", "mirt_get_stats", "mirt_surface_register", "mirt_surface_unregister", "mirt_raytrace_async", "mirt_rasterise_async",
     "mirt_band_of", "mirt_band_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_comm_selfcheck", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
 )
 
@@ -83,6 +83,8 @@ def load():
     lib.mirt_get_stats.argtypes = [C.POINTER(Stats)]
     lib.mirt_surface_register.argtypes = [_vp, C.c_size_t]
     lib.mirt_surface_unregister.argtypes = [_vp]
+    lib.mirt_raytrace_async.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int]
+    lib.mirt_rasterise_async.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, _vp, C.c_int]
     lib.mirt_band_of.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mirt_band_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]
     lib.mirt_comm_create_id.argtypes = [_vp]
@@ -344,6 +346,24 @@ def prepared_rasterise_device(view, lights7, indirect, y0, y1, row_origin, d_xrg
     fn = lib.mirt_rasterise_device
 
     def launch(_keep=(view, larr, ind)):
+        rc = fn(*args)
+        if rc:
+            _check(rc)
+    return launch
+
+
+def prepared_async(kind, view, lights7, indirect, mode, surface):
+    """Zero-argument callable: one asynchronous frame into `surface`, a numpy array inside a registered surface
+    (mirt_raytrace_async / mirt_rasterise_async); mirt.sync() completes it."""
+    lib = load()
+    larr, nl = make_lights(lights7)
+    ind = np.asarray(indirect, np.float32).copy()
+    if kind == "rt":
+        fn, args = lib.mirt_raytrace_async, (C.byref(view), larr, nl, _ptr(ind), int(mode), _ptr(surface), int(surface.strides[0]))
+    else:
+        fn, args = lib.mirt_rasterise_async, (C.byref(view), larr, nl, _ptr(ind), _ptr(surface), int(surface.strides[0]))
+
+    def launch(_keep=(view, larr, ind, surface)):
         rc = fn(*args)
         if rc:
             _check(rc)

@@ -127,6 +127,18 @@ MIRT_API int mirt_set_frames_in_flight(int frames);
 MIRT_API int mirt_surface_register(void *pixels, size_t bytes);
 MIRT_API int mirt_surface_unregister(void *pixels);
 
+/* Asynchronous frames into a registered surface: the frame is rendered and copied (one stream-ordered DMA copy into the
+ * pinned pages) on the library stream and the call returns as soon as both are queued; mirt_sync() -- the SDL_UpdateRect of the
+ * loop (raytracer.cpp:653, rasteriser.cpp:528) -- completes it.  With mirt_set_frames_in_flight(2) the copy of frame i overlaps
+ * the render of frame i + 1, which is what makes the host boundary run at the rate of the link (bench.py host_path.async):
+ * consecutive frames then need DIFFERENT surfaces (double buffering), exactly as the *_device calls do.  out_xrgb must lie in a
+ * surface registered above (MIRT_ERR_INVALID_ARGUMENT otherwise: pageable memory cannot take a stream-ordered copy).  Same
+ * pixels as mirt_raytrace / mirt_rasterise: interior only for the ray tracer, the whole surface for the rasteriser. */
+MIRT_API int mirt_raytrace_async(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                 int mode, uint32_t *out_xrgb, int pitch_bytes);
+MIRT_API int mirt_rasterise_async(const mirt_view *view, const mirt_light *lights, int nlights, const float *indirect,
+                                  uint32_t *out_xrgb, int pitch_bytes);
+
 /* ---- scene --------------------------------------------------------------------------------------- */
 
 /* Replaces the global `vector<Triangle> triangles` (raytracer.cpp:28, rasteriser.cpp:64): copies n

@@ -337,10 +337,11 @@ def test_errors_are_reported_not_fatal():
 
 # ---- the C++ host adapter (reference-shaped Draw()) ---------------------------------------------------
 
-@pytest.mark.parametrize("which", ["rt", "rtsoft", "rtaa", "rtdof", "raster", "rasterdof"])
+@pytest.mark.parametrize("which", ["rt", "rtsoft", "rtaa", "rtdof", "raster", "rasterdof", "rtasync", "rasterasync"])
 def test_host_draw_adapter_matches_oracle(oracle, tmp_path, which):
     """cpp-raytracer-rasterizer_amd/host/demo_main runs the reference's main loop shape (Update(); Draw();) through
-    mirt_draw.hpp and the C-ABI; its surface must hold exactly the words the oracle's PutPixelSDL path produces."""
+    mirt_draw.hpp and the C-ABI; its surface must hold exactly the words the oracle's PutPixelSDL path produces.
+    (*async: eight DrawAsync() frames into two registered surfaces in turn, two in flight, the last one the reference view.)"""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -355,6 +356,7 @@ def test_host_draw_adapter_matches_oracle(oracle, tmp_path, which):
         mirt.init(0)
     got = np.fromfile(raw, np.uint32).reshape(H, W)
     tris = oracle.cornell()
+    which = which.replace("async", "")
     if which == "rt":
         ref = oracle.raytrace(tris, (0, 0, -2), oracle.rot_from_yaw(0.0, 1.0), H / 2.0, W, H, DEFAULT_LIGHT)["xrgb"]
     elif which == "rtdof":
@@ -880,6 +882,62 @@ mirt.shutdown()
 print("ok")
 """ % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-raytracer-rasterizer_amd"),
        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    env = dict(os.environ, MIRT_HOST_PATH=path)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("path", ["direct", "dma"])
+def test_asynchronous_frames_into_registered_surfaces(path):
+    """mirt_raytrace_async / mirt_rasterise_async: frames queued without a host sync into two registered surfaces in turn (two
+    frames in flight: the copy of one overlaps the render of the next), completed by mirt_sync -- every surface then holds the
+    words the synchronous call delivers for its view, pitch wider than the frame, border untouched; a surface that is not
+    registered is refused.  In a child process: the delivery mode is read once."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path[:0] = [%r]
+import mirt
+mirt.init(0)
+L = mirt.DEFAULT_LIGHT
+W, H, PW = 333, 207, 352
+for kind in ("rt", "rtbinned", "raster", "rtdof"):
+    tris = mirt.scene_cornell() if kind != "rtbinned" else np.concatenate([mirt.scene_cornell(), mirt.scene_soup(3, 500, 0.1)])
+    views = [mirt.make_view((0.1 + 0.02 * i, 0, -2.5), mirt.rot_from_yaw(0.2, 1.01 if kind == "raster" else 1.0), 150.0, W, H) for i in range(6)]
+    mirt.scene_upload(tris, mirt.cull(tris, views[0], 0) if kind == "raster" else None)
+    mirt.set_depth_of_field(8 if kind == "rtdof" else 0, 1.3)
+    mode = mirt.RT_BINNED if kind == "rtbinned" else mirt.RT_AUTO
+    mirt.set_frames_in_flight(1)
+    want = []
+    for v in views:
+        x = np.full((H, PW), 0xABCDEF01, np.uint32)
+        (mirt.rasterise(v, L, xrgb=x[:, :W]) if kind == "raster" else mirt.raytrace(v, L, mode=mode, xrgb=x[:, :W]))
+        want.append(x)
+    big = np.full((len(views), H, PW), 0xABCDEF01, np.uint32)         # one registration, six surfaces inside it
+    mirt.surface_register(big)
+    for fl in (1, 2):
+        big[:] = 0xABCDEF01
+        mirt.set_frames_in_flight(fl)
+        calls = [mirt.prepared_async("raster" if kind == "raster" else "rt", v, L, (0.2, 0.2, 0.2), mode, big[i][:, :W]) for i, v in enumerate(views)]
+        for c in calls:
+            c()
+        mirt.sync()
+        for i in range(len(views)):
+            assert np.array_equal(big[i], want[i]), (kind, fl, i, int((big[i] != want[i]).sum()))
+    mirt.set_frames_in_flight(1)
+    loose = np.full((H, PW), 0xABCDEF01, np.uint32)
+    try:
+        mirt.prepared_async("raster" if kind == "raster" else "rt", views[0], L, (0.2, 0.2, 0.2), mode, loose[:, :W])()
+        raise SystemExit("an unregistered surface was accepted")
+    except mirt.MirtError as e:
+        assert "registered" in str(e)
+    mirt.surface_unregister(big)
+mirt.set_depth_of_field(0)
+mirt.shutdown()
+print("ok")
+""" % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-raytracer-rasterizer_amd"),)
     env = dict(os.environ, MIRT_HOST_PATH=path)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
