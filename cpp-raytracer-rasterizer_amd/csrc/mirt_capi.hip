@@ -450,6 +450,10 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         bs.bucket_cnt = bcnt; bs.nbuckets = nbuckets; bs.bucket_shift = bucket_sort_shift(bs.nbins);
     }
     const size_t bin_lds = bucket_sort ? (size_t)nbuckets * sizeof(uint32_t) : 0;
+    {   // k_bin_pairs: ~52 KB of static LDS + up to 32 KB of bucket counters: past the 64 KB a launch may use by default
+        static const bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); return true; }();
+        (void)once;
+    }
     if (guess) {
         // room for half as many pairs again as the last frame seen produced; growing needs this stream idle (rare)
         const size_t want = (size_t)S.known_pairs + S.known_pairs / 2 + 4096;
@@ -467,7 +471,7 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         if (attempt) HIP_TRY(hipMemsetAsync(counter, 0, 4, g.stream));
         if (bucket_sort && (attempt || S.bucket_dirty)) HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (size_t)S.cap_buckets, g.stream));
         S.bucket_dirty = bucket_sort;                        // bucket counts pending until k_bs_local has consumed them
-        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(256), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
+        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(BIN_WG), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
         if (!fresh) break;
         if (guess) {
             // no sync: the count travels to pinned memory behind the kernel and a later frame picks it up

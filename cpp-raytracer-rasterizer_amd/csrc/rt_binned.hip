@@ -104,7 +104,8 @@ __device__ __forceinline__ bool bin_jointly_empty(const BinLin (&G)[4], float u0
 
 struct BinFrameGrid { int nbu, fj0, fj1, cells_x, cy0, ncell; uint32_t fbase, nshell; };
 
-constexpr int BIN_PAIR_BUF = 2048;                    // pairs a workgroup stages in LDS between flushes (16 KiB)
+constexpr int BIN_PAIR_BUF = 4096;                    // pairs a workgroup stages in LDS between flushes (32 KiB)
+constexpr int BIN_TESTS_PER_THREAD = 2;               // flattened bin tests a thread runs per round (independent chains: their LDS latencies overlap)
 constexpr int BIN_DIRECT_SIDE = 32;                   // boxes up to 32 x 32 bins are tested bin by bin, flattened over the workgroup
 
 // Where the pairs of the huge items go: the workgroup's LDS buffer, allocated with an LDS atomic per level-2 step, and
@@ -185,18 +186,16 @@ __device__ __forceinline__ void bin_walk_large(const BinItem &u, uint32_t utri, 
 #endif
 }
 
-// what the flattened bin-by-bin tests need of a direct item, in LDS
-struct BinDirect {
-    float4 A2, Bu, Bv, box;       // box = {lou, hiu, lov, hiv}
-};
+// What the flattened bin-by-bin tests need of a direct item, in LDS: A2, Bu, Bv and box = {lou, hiu, lov, hiv}, one array per
+// field (neighbouring lanes read neighbouring items: 16-byte stride, where a 64-byte record put them on the same banks).
 
-__global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
+__global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
                                                    const OriginRow *__restrict__ light_tab, int n, BinSet bs, BinPairs out)
 {
     // pairs per bucket (bin >> bucket_shift) for the sort that follows (bin_bucket_sort.hip): bs.bucket_cnt != NULL
     extern __shared__ uint32_t s_bucket[];
     __shared__ uint32_t s_keys[BIN_PAIR_BUF], s_vals[BIN_PAIR_BUF];
-    __shared__ BinDirect s_item[256];
+    __shared__ float4 s_A2[256], s_Bu[256], s_Bv[256], s_box[256];
     __shared__ uint32_t s_org[256];                   // i_lo | j_lo << 16 of a direct item's box
     __shared__ uint32_t s_ni[256];                    // its width in bins
     __shared__ uint32_t s_pre[257];                   // exclusive prefix of the box sizes
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
     const int nchunks = (n + chunk_tris - 1) / chunk_tris, nwork = nchunks * bs.nframes;
     if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
     if (bs.bucket_cnt)
-        for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += 256) s_bucket[b] = 0u;
+        for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += BIN_WG) s_bucket[b] = 0u;
 
     // hands the staged pairs over to the global list (called by all threads)
     auto flush = [&]() {
@@ -219,14 +218,14 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         if (threadIdx.x == 0 && staged) s_base = atomicAdd(&bs.counters[0], staged);
         __syncthreads();
         const uint32_t base = s_base;
-        for (uint32_t i = threadIdx.x; i < staged; i += 256) {
+        for (uint32_t i = threadIdx.x; i < staged; i += BIN_WG) {
             const uint32_t at = base + i;
             if (at < out.cap) { out.keys[at] = s_keys[i]; out.vals[at] = s_vals[i]; }
             if (bs.bucket_cnt) atomicAdd(&s_bucket[s_keys[i] >> bs.bucket_shift], 1u);
         }
         __syncthreads();
         if (bs.bucket_cnt && staged)
-            for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += 256) {
+            for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += BIN_WG) {
                 const uint32_t c = s_bucket[b];
                 if (c) { atomicAdd(&bs.bucket_cnt[b], c); s_bucket[b] = 0u; }
             }
@@ -346,20 +345,18 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
             if (lane >= d) incl += o;
         }
         __syncthreads();                              // the previous work item's readers of the LDS tables are done
-        if (lane == 63) s_wave[wave] = incl;
+        if (lane == 63 && wave < 4) s_wave[wave] = incl;     // (the triangles of an item sit in the first four waves)
         if (kind == 1) {
-            BinDirect d;
-            d.A2 = make_float4(it.A2[0], it.A2[1], it.A2[2], it.A2[3]);
-            d.Bu = make_float4(it.Bu[0], it.Bu[1], it.Bu[2], it.Bu[3]);
-            d.Bv = make_float4(it.Bv[0], it.Bv[1], it.Bv[2], it.Bv[3]);
-            d.box = make_float4(it.lou, it.hiu, it.lov, it.hiv);
-            s_item[threadIdx.x] = d;
+            s_A2[threadIdx.x] = make_float4(it.A2[0], it.A2[1], it.A2[2], it.A2[3]);
+            s_Bu[threadIdx.x] = make_float4(it.Bu[0], it.Bu[1], it.Bu[2], it.Bu[3]);
+            s_Bv[threadIdx.x] = make_float4(it.Bv[0], it.Bv[1], it.Bv[2], it.Bv[3]);
+            s_box[threadIdx.x] = make_float4(it.lou, it.hiu, it.lov, it.hiv);
             s_org[threadIdx.x] = (uint32_t)i_lo | ((uint32_t)j_lo << 16);
             s_ni[threadIdx.x] = ni | (shell << 8);
         }
         __syncthreads();
         const uint32_t t0w = s_wave[0], t1w = s_wave[1], t2w = s_wave[2], t3w = s_wave[3];
-        s_pre[threadIdx.x] = (wave > 0 ? t0w : 0u) + (wave > 1 ? t1w : 0u) + (wave > 2 ? t2w : 0u) + incl - nb;
+        if (threadIdx.x < 256) s_pre[threadIdx.x] = (wave > 0 ? t0w : 0u) + (wave > 1 ? t1w : 0u) + (wave > 2 ? t2w : 0u) + incl - nb;
         const uint32_t T = t0w + t1w + t2w + t3w;
         if (threadIdx.x == 0) s_pre[256] = T;
 
@@ -369,53 +366,64 @@ __global__ __launch_bounds__(256) void k_bin_pairs(const float *__restrict__ tri
         { const unsigned long long md = __ballot(kind == 1); if (lane == 0) atomicAdd(&bs.counters[10], (uint32_t)__popcll(md)); }
 #endif
         STAMP(st_prefix)
-        // ---- flattened bin-by-bin tests: thread t of a round takes test t ----
-        for (uint32_t r0 = 0; r0 < T; r0 += 256) {
+        // ---- flattened bin-by-bin tests: thread t of a round takes tests t, t + BIN_WG, ... ----
+        constexpr int TPT = BIN_TESTS_PER_THREAD;
+        for (uint32_t r0 = 0; r0 < T; r0 += BIN_WG * TPT) {
 #ifdef MIRT_BIN_STAMPS
             st_nrounds++;
 #endif
             __syncthreads();                          // s_pre written / the previous round's appends counted
-            if (s_fill + 256u > (uint32_t)BIN_PAIR_BUF) flush();
-            const uint32_t t = r0 + threadIdx.x;
-            bool pass = false;
-            uint32_t key = 0, val = 0;
-            if (t < T) {
-                uint32_t lo = 0, hi = 256;            // the item whose range [s_pre[i], s_pre[i+1]) holds t
+            if (s_fill + (uint32_t)(BIN_WG * TPT) > (uint32_t)BIN_PAIR_BUF) flush();
+            bool pass[TPT];
+            uint32_t key[TPT], val[TPT];
 #pragma unroll
-                for (int step = 0; step < 8; step++) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_pre[mid] <= t) lo = mid; else hi = mid;
+            for (int q = 0; q < TPT; q++) {
+                const uint32_t t = r0 + (uint32_t)(q * BIN_WG) + threadIdx.x;
+                pass[q] = false; key[q] = 0; val[q] = 0;
+                if (t < T) {
+                    uint32_t lo = 0, hi = 256;            // the item whose range [s_pre[i], s_pre[i+1]) holds t
+#pragma unroll
+                    for (int step = 0; step < 8; step++) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pre[mid] <= t) lo = mid; else hi = mid;
+                    }
+                    const uint32_t nis = s_ni[lo], wi = nis & 0xFFu, sh = nis >> 8;
+                    const uint32_t b = t - s_pre[lo], org = s_org[lo];
+                    const uint32_t recip = 65536u / wi + 1u;             // b / wi == (b * recip) >> 16 for b < 1024, wi <= 32
+                    const uint32_t dj = (b * recip) >> 16, di = b - dj * wi;
+                    const int i = (int)(org & 0xFFFFu) + (int)di, j = (int)(org >> 16) + (int)dj;
+                    const float4 A2 = s_A2[lo], Bu = s_Bu[lo], Bv = s_Bv[lo], box = s_box[lo];
+                    const float FI = (float)i, FJ = (float)j;
+                    pass[q] = (__builtin_fmaf(FJ, Bv.x, __builtin_fmaf(FI, Bu.x, A2.x)) >= 0.0f) &&
+                              (__builtin_fmaf(FJ, Bv.y, __builtin_fmaf(FI, Bu.y, A2.y)) >= 0.0f) &&
+                              (__builtin_fmaf(FJ, Bv.z, __builtin_fmaf(FI, Bu.z, A2.z)) >= 0.0f) &&
+                              (__builtin_fmaf(FJ, Bv.w, __builtin_fmaf(FI, Bu.w, A2.w)) >= 0.0f) &&
+                              (FI + 1.0f >= box.x) && (FI <= box.y) && (FJ + 1.0f >= box.z) && (FJ <= box.w);   // = cell_may_hit(.., A2, i, j, 1)
+                    key[q] = (gr.fbase + (uint32_t)j * (uint32_t)nbu + (uint32_t)i) * gr.nshell + sh;
+                    val[q] = tri0 + lo;
                 }
-                const uint32_t nis = s_ni[lo], wi = nis & 0xFFu, sh = nis >> 8;
-                const uint32_t b = t - s_pre[lo], org = s_org[lo];
-                const uint32_t recip = 65536u / wi + 1u;             // b / wi == (b * recip) >> 16 for b < 1024, wi <= 32
-                const uint32_t dj = (b * recip) >> 16, di = b - dj * wi;
-                const int i = (int)(org & 0xFFFFu) + (int)di, j = (int)(org >> 16) + (int)dj;
-                const BinDirect d = s_item[lo];
-                const float FI = (float)i, FJ = (float)j;
-                pass = (__builtin_fmaf(FJ, d.Bv.x, __builtin_fmaf(FI, d.Bu.x, d.A2.x)) >= 0.0f) &&
-                       (__builtin_fmaf(FJ, d.Bv.y, __builtin_fmaf(FI, d.Bu.y, d.A2.y)) >= 0.0f) &&
-                       (__builtin_fmaf(FJ, d.Bv.z, __builtin_fmaf(FI, d.Bu.z, d.A2.z)) >= 0.0f) &&
-                       (__builtin_fmaf(FJ, d.Bv.w, __builtin_fmaf(FI, d.Bu.w, d.A2.w)) >= 0.0f) &&
-                       (FI + 1.0f >= d.box.x) && (FI <= d.box.y) && (FJ + 1.0f >= d.box.z) && (FJ <= d.box.w);   // = cell_may_hit(.., A2, i, j, 1)
-                key = (gr.fbase + (uint32_t)j * (uint32_t)nbu + (uint32_t)i) * gr.nshell + sh;
-                val = tri0 + lo;
             }
-            const unsigned long long m = __ballot(pass);
-            if (m) {
+            // one LDS atomic per wave and round hands out the slots of all its passing tests
+            unsigned long long m[TPT];
+            uint32_t off[TPT], cnt = 0;
+#pragma unroll
+            for (int q = 0; q < TPT; q++) { m[q] = __ballot(pass[q]); off[q] = cnt; cnt += (uint32_t)__popcll(m[q]); }
+            if (cnt) {
                 uint32_t at0 = 0;
-                if (lane == 0) at0 = atomicAdd(&s_fill, (uint32_t)__popcll(m));
+                if (lane == 0) at0 = atomicAdd(&s_fill, cnt);
                 at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
-                if (pass) {
-                    const uint32_t at = at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    s_keys[at] = key; s_vals[at] = val;               // fits: the round started with room for 256
-                }
+#pragma unroll
+                for (int q = 0; q < TPT; q++)
+                    if (pass[q]) {
+                        const uint32_t at = at0 + off[q] + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull));
+                        s_keys[at] = key[q]; s_vals[at] = val[q];         // fits: the round started with room for BIN_WG * TPT
+                    }
             }
         }
 
         STAMP(st_rounds)
         // ---- huge items: the wave walks them one at a time, pairs into the same LDS buffer ----
-        __syncthreads();                              // no flattened round (which counts on its 256 free slots) is still appending
+        __syncthreads();                              // no flattened round (which counts on its BIN_WG * TPT free slots) is still appending
         {
             BinLargeSink sink = { s_keys, s_vals, &s_fill, &s_valid, &bs.counters[0], out, bs.bucket_cnt, bs.bucket_shift };
             for (unsigned long long ml = __ballot(kind == 2); ml;) {

@@ -28,6 +28,8 @@ namespace mirt {
 
 constexpr int BIN_TILE = 8;            // camera bins are 8x8 pixels = one wave64
 constexpr int BIN_COARSE = 8;          // coarse cell = 8x8 fine bins (the three-level walk of huge items, rt_binned.hip)
+constexpr int BIN_WG = 512;            // threads of a k_bin_pairs workgroup: a work item's 256 triangles are set up by the first four waves, the
+                                       // flattened bin tests and the flushes run on all eight (two waves per SIMD issue twice as fast as one)
 constexpr int CUBE_BINS_MIN = 64;      // per-face light-cube grid is B x B; B = 64 by default (128 / 256 selectable)
 constexpr int MAX_BIN_FRAMES = 1 + 6 * MIRT_MAX_LIGHTS;
 
