@@ -326,7 +326,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
         return time.perf_counter() - t0
 
     # calibrate the batch: frames per step so that the timed region lasts >= target_s (agreed over the ranks)
-    timed(2 * batch if world > 1 else 4)
+    timed(max(2 * batch, 12))                          # (also past the frames after which the light-cube grid settles: mirt_capi light_cache_ensure)
     probe_frames = max(2 * batch, 8)
     t_frame = timed(probe_frames) / probe_frames
     t_frame = env.reduce([t_frame], dist.ReduceOp.MAX)[0] if world > 1 else t_frame
@@ -515,10 +515,14 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                      "algorithmic_bytes": int(algo_bytes),
                                      "kernel_ms_sum": round(sum(kernel_ms.get(k, 0.0) for k in ("clear", "raster_setup", "raster_frag", "raster_resolve")), 5)}
         if world == 1 and want_cpu:
-            out["cpu_baseline"] = cpu_baseline(kind, tris, culled0, W, H, cam, mirt.rot_from_yaw(0.0, rot11), focal, samples=soft_samples, jitter=soft_jitter, aa=aa,
-                                               budget_s=12.0 if extras else 5.0)
-            if dof:
-                out["cpu_baseline"]["sample"] += "; per-pixel path only, the depth-of-field blur is not part of the CPU sample"
+            # deferred (main() runs it after every GPU measurement of the line): tens of seconds of host-only work let the GPU
+            # drop its clocks, and the workload timed next would start on a cold device
+            def cpu_leg(rot=mirt.rot_from_yaw(0.0, rot11)):
+                r = cpu_baseline(kind, tris, culled0, W, H, cam, rot, focal, samples=soft_samples, jitter=soft_jitter, aa=aa, budget_s=12.0 if extras else 5.0)
+                if dof:
+                    r["sample"] += "; per-pixel path only, the depth-of-field blur is not part of the CPU sample"
+                return r
+            out["_cpu_leg"] = cpu_leg
     mirt.set_soft_shadows(1)
     mirt.set_antialiasing(1)
     mirt.set_depth_of_field(0)
@@ -628,9 +632,14 @@ def main():
             r = run_workload(env, sub, max(4, steps // 2), 1, "auto", not args.static_camera, not args.no_cpu_baseline, target_s=0.07, extras=False)
             if r is not None:
                 subs[sub] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_frame", "frames_per_s", "frames_per_step", "steps", "timed_region_s",
-                                               "kernel_ms_rank0", "config", "roofline", "cpu_baseline") if k in r}
+                                               "kernel_ms_rank0", "config", "roofline", "_cpu_leg") if k in r}
         if out is not None:
             out["sub_results"] = subs
+    # the CPU legs, after all GPU timing
+    for rec in ([out] if out is not None else []) + list((out or {}).get("sub_results", {}).values()):
+        leg = rec.pop("_cpu_leg", None)
+        if leg is not None:
+            rec["cpu_baseline"] = leg()
     if env.rank == 0:
         print(json.dumps(out), flush=True)
     if env.world > 1:

@@ -1,21 +1,30 @@
 #!/usr/bin/env bash
-# tools/collect_profiles.sh -- (GPU box) every record kept under profiles/ for a round, in one go: bench lines with
-# cpu_baseline, rocprofv3 kernel stats, the HBM-traffic PMC passes and the issue-side PMC passes.  Results land in
-# gpurun_out/; tools/store_profiles.py copies the summaries into profiles/ afterwards (in the build container).
+# tools/collect_profiles.sh pmc|bench -- (GPU box) every record kept under profiles/ for a round, in two gpurun calls:
+#   pmc    rocprofv3 kernel stats, the HBM-traffic PMC passes and the issue-side PMC passes of the three default workloads,
+#          the microbenchmarks, the binned-vs-brute fuzz and the moving-light run;
+#   bench  the bench lines (with cpu_baseline) -- AFTER `python tools/store_profiles.py <tag>` has put the PMC summaries of
+#          the first call into profiles/, which is where bench.py reads `roofline.traffic` from.
+# Results land in gpurun_out/; tools/store_profiles.py copies the summaries into profiles/ (in the build container).
 set -uo pipefail
-python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench default rc=$?"
-for w in cornell1080 soup100k raster4k cornell500 cornell1080soft16 cornell1080aa3 cornell1080dof8 raster4kdof8; do
-  python bench.py --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err; echo "bench $w rc=$?"
-done
-python bench.py --workload soup1m8k --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_soup1m8k.json 2>/dev/null; echo "bench soup1m8k rc=$?"
-python bench.py --workload soup100k --mode brute --steps 2 --warmup 1 --no-cpu-baseline --static-camera > gpurun_out/bench_soup100k_brute.json 2>/dev/null; echo "bench soup100k brute rc=$?"
-for t in cornell1080 soup100k raster4k; do
-  tools/prof.sh $t --workload $t --steps 20 --warmup 3 > /dev/null 2>&1
-  tools/pmc_hbm.sh $t --workload $t --steps 10 --warmup 2 > /dev/null 2>&1
-  python tools/pmc_summary.py gpurun_out/pmc_$t > gpurun_out/pmc_$t/summary.json
-  tools/pmc_valu.sh $t --workload $t --steps 10 --warmup 2 > gpurun_out/pmcv_$t.txt 2>&1
-  python tools/pmc_issue_summary.py gpurun_out/pmcv_$t > gpurun_out/pmcv_$t/summary.json
-done
-tools/ubench > gpurun_out/ubench.txt 2>&1
-tools/edgebench > gpurun_out/edgebench.txt 2>&1
+stage="${1:-pmc}"
+if [ "$stage" = pmc ]; then
+  for t in cornell1080 soup100k raster4k; do
+    tools/prof.sh $t --workload $t --steps 20 --warmup 3 > /dev/null 2>&1; echo "trace $t rc=$?"
+    tools/pmc_hbm.sh $t --workload $t --steps 10 --warmup 2 > /dev/null 2>&1
+    python tools/pmc_summary.py gpurun_out/pmc_$t > gpurun_out/pmc_$t/summary.json
+    tools/pmc_valu.sh $t --workload $t --steps 10 --warmup 2 > gpurun_out/pmcv_$t.txt 2>&1
+    python tools/pmc_issue_summary.py gpurun_out/pmcv_$t > gpurun_out/pmcv_$t/summary.json; echo "pmc $t rc=$?"
+  done
+  tools/ubench > gpurun_out/ubench.txt 2>&1
+  tools/edgebench > gpurun_out/edgebench.txt 2>&1
+  python tools/moving_light.py > gpurun_out/moving_light.txt 2>&1; echo "moving light rc=$?"
+  python tools/fuzz_binned.py 0 300 > gpurun_out/fuzz_binned_vs_brute.txt 2>&1; echo "fuzz rc=$?"
+else
+  python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench default rc=$?"
+  for w in cornell1080 soup100k raster4k cornell500 cornell1080soft16 cornell1080aa3 cornell1080dof8 raster4kdof8; do
+    python bench.py --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err; echo "bench $w rc=$?"
+  done
+  python bench.py --workload soup1m8k --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_soup1m8k.json 2>/dev/null; echo "bench soup1m8k rc=$?"
+  python bench.py --workload soup100k --mode brute --steps 2 --warmup 1 --no-cpu-baseline --static-camera > gpurun_out/bench_soup100k_brute.json 2>/dev/null; echo "bench soup100k brute rc=$?"
+fi
 echo done
