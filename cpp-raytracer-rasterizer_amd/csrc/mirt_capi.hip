@@ -51,7 +51,7 @@ struct RtTraceFrame {
     uint32_t pair_cap;
 };
 template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
-__global__ void k_rt_brute_guard(const RtFrame, const uint32_t *, uint32_t);
+__global__ void k_rt_brute_guard(const RtFrame, const uint32_t *, uint32_t, int, int);
 __global__ void k_geo_table(const float *, int, GeoRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *);
 size_t rt_trace_lds_bytes();
@@ -710,9 +710,9 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         bf.cam_tab = S.d_cam_tab;
         bf.light_tab = g.lc.d_light_tab;
         bf.unsafe = nullptr;
-        const int rows = y1 - y0;
-        const size_t blds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
-        hipLaunchKernelGGL(k_rt_brute_guard, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), blds, g.stream, bf, S.d_bin_counters, S.cap_used);
+        const int rows = y1 - y0, nbx = (view->width + 127) / 128, nby = (rows + 3) / 4;
+        hipLaunchKernelGGL(k_rt_brute_guard, dim3((unsigned)std::min<long long>((long long)nbx * nby, (long long)g.cu_count * 4)), dim3(256), 0, g.stream,
+                           bf, S.d_bin_counters, S.cap_used, nbx, nby);
     }
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());

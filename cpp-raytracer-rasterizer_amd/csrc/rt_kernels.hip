@@ -45,12 +45,14 @@ __global__ __launch_bounds__(256) void k_prep_origin(const float *__restrict__ t
 // The origin table is staged through LDS in chunks of CHUNK rows (48 B each); all 64 lanes read the same
 // row => three conflict-free ds_read_b128 broadcasts per triangle, reused for the lane's P rays.
 constexpr int RT_CHUNK = RT_CHUNK_ROWS;
+constexpr int GUARD_CHUNK = 128;            // origin rows per LDS chunk of k_rt_brute_guard
 
-template <int P, bool FILTER, bool AA>
-__device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
+// (bx, by) = the block of P*64 x 4 pixels; CHUNK = origin rows staged in LDS at a time
+template <int P, bool FILTER, bool AA, int CHUNK = RT_CHUNK>
+__device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab, int bx, int by)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int y = f.y0 + (int)blockIdx.y * 4 + wave;
+    const int y = f.y0 + by * 4 + wave;
     const bool row_ok = y < f.y1;
     const v3 cam = ld3(f.cam);
     const float halfW = (float)f.W / 2.0f, halfH = (float)f.H / 2.0f;
@@ -63,7 +65,7 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
     int best_i[P];
 #pragma unroll
     for (int p = 0; p < P; p++) {
-        xs[p] = ((int)blockIdx.x * P + p) * 64 + lane;
+        xs[p] = (bx * P + p) * 64 + lane;
         ok[p] = row_ok && xs[p] < f.W;
         best_d[p] = FLT_MAX;                              // Update() reset (:335-339), once per frame
         best_i[p] = -1;
@@ -86,8 +88,8 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
             }
 
             // ---------------- primary sub-ray: closest hit so far, ties -> later index (:243) ----------------
-            for (int base = 0; base < f.n; base += RT_CHUNK) {
-                const int cnt = min(RT_CHUNK, f.n - base);
+            for (int base = 0; base < f.n; base += CHUNK) {
+                const int cnt = min(CHUNK, f.n - base);
                 __syncthreads();
                 {
                     const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + base);
@@ -151,8 +153,8 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab)
                 const OriginRow *tab = f.light_tab + (size_t)k * f.n;
                 // every wave of the block must take part in the staging barriers, so the chunk loop is
                 // unconditional; a wave with nothing left to test just skips the inner loop.
-                for (int base = 0; base < f.n; base += RT_CHUNK) {
-                    const int cnt = min(RT_CHUNK, f.n - base);
+                for (int base = 0; base < f.n; base += CHUNK) {
+                    const int cnt = min(CHUNK, f.n - base);
                     __syncthreads();
                     {
                         const float4 *src = reinterpret_cast<const float4 *>(tab + base);
@@ -531,11 +533,11 @@ __global__ __launch_bounds__(256) void k_rt_brute(const RtFrame f)
     extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
     const bool safe = __builtin_amdgcn_readfirstlane(*f.unsafe) == 0u;
     if (f.aa > 1) {
-        if (safe) brute_body<P, true, true>(f, s_tab);
-        else brute_body<P, false, true>(f, s_tab);
+        if (safe) brute_body<P, true, true>(f, s_tab, (int)blockIdx.x, (int)blockIdx.y);
+        else brute_body<P, false, true>(f, s_tab, (int)blockIdx.x, (int)blockIdx.y);
     } else {
-        if (safe) brute_body<P, true, false>(f, s_tab);
-        else brute_body<P, false, false>(f, s_tab);
+        if (safe) brute_body<P, true, false>(f, s_tab, (int)blockIdx.x, (int)blockIdx.y);
+        else brute_body<P, false, false>(f, s_tab, (int)blockIdx.x, (int)blockIdx.y);
     }
 }
 
@@ -546,12 +548,17 @@ template __global__ void k_rt_brute<2>(const RtFrame);
 // this frame's binning produced more pairs than the list holds (*pair_count > pair_cap; the sort and k_rt_trace then do
 // nothing) the frame is rendered by brute force -- every ray against every triangle, same filter, same exact arithmetic, same
 // bits -- otherwise every workgroup leaves at once.  The host learns the count a frame later and grows the list.
-__global__ __launch_bounds__(256) void k_rt_brute_guard(const RtFrame f, const uint32_t *__restrict__ pair_count, uint32_t pair_cap)
+__global__ __launch_bounds__(256) void k_rt_brute_guard(const RtFrame f, const uint32_t *__restrict__ pair_count, uint32_t pair_cap, int nbx, int nby)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
+    // A small resident grid striding over the frame's pixel blocks, with a small LDS slice: what matters is how quickly the
+    // launch leaves in the frame that did NOT overflow -- with one workgroup per block and 48 KB of LDS each, 4050 workgroups
+    // had to find room among the other stream's trace kernel first (12 us per frame on the 100 k soup).
+    __shared__ __attribute__((aligned(16))) float4 s_tab[GUARD_CHUNK * 3];
     if (__builtin_amdgcn_readfirstlane(*pair_count) <= pair_cap) return;
-    if (f.aa > 1) brute_body<2, true, true>(f, s_tab);
-    else brute_body<2, true, false>(f, s_tab);
+    for (int b = blockIdx.x; b < nbx * nby; b += gridDim.x) {
+        if (f.aa > 1) brute_body<2, true, true, GUARD_CHUNK>(f, s_tab, b % nbx, b / nbx);
+        else brute_body<2, true, false, GUARD_CHUNK>(f, s_tab, b % nbx, b / nbx);
+    }
 }
 
 }  // namespace mirt
