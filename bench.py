@@ -175,10 +175,34 @@ class Env:
         # time); torch.distributed only carries the 128-byte group id to the ranks.  MIRT_BENCH_GATHER=torch keeps the gather
         # in Python (mirt/sharding.py, torch.distributed.gather) instead.
         self.native = self.world > 1 and os.environ.get("MIRT_BENCH_GATHER", "native") != "torch"
+        self.native_error = None
         if self.native:
-            ids = [mirt.comm_create_id() if self.rank == 0 else None]
+            # every rank reports whether its side of the group came up (id, communicator, a send + receive to itself through the
+            # transport); if any did not, all ranks fall back to the Python gather together rather than lose the run
+            try:
+                ids = [mirt.comm_create_id() if self.rank == 0 else None]
+            except mirt.MirtError as e:
+                ids, self.native_error = [None], str(e)
             dist.broadcast_object_list(ids, src=0)
-            mirt.comm_init(ids[0], self.rank, self.world)
+            if ids[0] is not None and self.native_error is None:
+                try:
+                    mirt.comm_init(ids[0], self.rank, self.world)
+                    mirt.comm_selfcheck(1 << 20)
+                except mirt.MirtError as e:
+                    self.native_error = str(e)
+            elif self.native_error is None:
+                self.native_error = "rank 0 could not create the group id"
+            flag = torch.tensor([0.0 if self.native_error is None else 1.0], device="cpu" if self.rehearsal else torch.device("cuda", local_rank))
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() != 0.0:
+                if self.native_error is None:
+                    self.native_error = "another rank could not join the group"
+                print("bench.py rank %d: library gather unavailable (%s); falling back to torch.distributed.gather" % (self.rank, self.native_error), file=sys.stderr, flush=True)
+                try:
+                    mirt.comm_shutdown()
+                except mirt.MirtError:
+                    pass
+                self.native = False
         self.dev = torch.device("cuda", local_rank)
         self.mirt_stream = torch.cuda.ExternalStream(mirt.load().mirt_stream(), device=self.dev)
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None

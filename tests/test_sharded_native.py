@@ -138,9 +138,19 @@ def test_sharded_frames_through_the_loopback_transport(tmp_path, world, root):
 SELF_CODE = r"""
 import os, sys, numpy as np
 sys.path[:0] = [%(pkg)r, %(tests)r]
+dist = None
 if sys.argv[1] == "torch":
-    import torch                              # the process then already holds PyTorch's librccl: the library must reuse it
-    torch.zeros(4, device="cuda:0").sum().item()
+    # as in bench.py --gpus N: the process runs torch.distributed over RCCL (its own communicator, made by an all_reduce)
+    # before AND after the library creates its group -- two users of RCCL in one process
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% (20000 + os.getpid() %% 20000), rank=0, world_size=1)
+    t = torch.ones(4, device="cuda:0")
+    dist.all_reduce(t)
+    assert t.sum().item() == 4.0
+    ids = [None]
+    dist.broadcast_object_list(ids, src=0)    # how bench.py hands the group id to the ranks
 import mirt
 from devbuf import DeviceArray
 mirt.init(0)
@@ -161,8 +171,15 @@ for i, v in enumerate(views):
     ref = DeviceArray((H, W), np.uint32, 0x33)
     mirt.raytrace_device(v, L, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, ref.ptr, W * 4)
     assert np.array_equal(got[i], ref.read())
+if dist is not None:
+    t = torch.ones(4, device="cuda:0")
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    assert t.sum().item() == 4.0
 mirt.comm_shutdown()
 mirt.shutdown()
+if dist is not None:
+    dist.destroy_process_group()
 print("selfcheck ok", flush=True)
 """
 
