@@ -70,6 +70,25 @@ __device__ __forceinline__ bool exact_hit_geo(const TestDots &d, float e1e2b, co
     return false;
 }
 
+// The same for the two pixels of a lane at once (k_rt_tile2): the six divisions as three packed pairs, the triangle's geometry
+// read once, hit points and distances in packed arithmetic -- operation for operation what exact_hit_geo does per half.  A half
+// the filter rejected computes values nobody reads (its `m` is false), like an inactive lane.
+__device__ __forceinline__ void exact_hit_geo2(const TestDots2 &d, float e1e2b, const float4 *geo, v3 start, bool m0, bool m1,
+                                               bool *hit0, bool *hit1, v3p *pos, f2 *dist)
+{
+    const f2 t = div2(splat2(e1e2b), d.den), u = div2(d.pu, d.den), v = div2(d.qv, d.den);     // raytracer.cpp:237
+    const f2 uv = u + v;
+    *hit0 = m0 && uv.x <= 1.0f && u.x >= 0.0f && v.x >= 0.0f && t.x >= 0.0f;                     // :239
+    *hit1 = m1 && uv.y <= 1.0f && u.y >= 0.0f && v.y >= 0.0f && t.y >= 0.0f;
+    if (*hit0 || *hit1) {
+        const float4 g0 = geo[0], g1 = geo[1], g2 = geo[2];
+        const v3p v0 = splat3(V3(g0.x, g0.y, g0.z)), e1 = splat3(V3(g0.w, g1.x, g1.y)), e2 = splat3(V3(g1.z, g1.w, g2.x));
+        const v3p p = add3p(add3p(v0, scale3p(e1, u)), scale3p(e2, v));                         // :241
+        *pos = p;
+        *dist = distance3p(splat3(start), p);                                                    // :242
+    }
+}
+
 template <int TW, bool AA>
 __device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty, const float4 *s_cam, const float4 *s_geo,
                                           const float4 *s_fns, const float4 *s_shade, const float4 *s_light)
@@ -338,15 +357,17 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
             bool m0, m1;
             maybe_hit2(td, &m0, &m1);
             if (m0 || m1) {
-                v3 hp;
-                float dist;
-                if (m0 && exact_hit_geo(dots_half(td, 0), r0.w, tb.geo + 3 * j, cam, &hp, &dist)) {
+                v3p hp;
+                f2 dist;
+                bool h0, h1;
+                exact_hit_geo2(td, r0.w, tb.geo + 3 * j, cam, m0, m1, &h0, &h1, &hp, &dist);
+                if (h0) {
                     any0 = true;
-                    if (bd0 >= dist) { bd0 = dist; bi0 = j; pos0 = hp; }      // :243-247
+                    if (bd0 >= dist.x) { bd0 = dist.x; bi0 = j; pos0 = half0(hp); }      // :243-247
                 }
-                if (m1 && exact_hit_geo(dots_half(td, 1), r0.w, tb.geo + 3 * j, cam, &hp, &dist)) {
+                if (h1) {
                     any1 = true;
-                    if (bd1 >= dist) { bd1 = dist; bi1 = j; pos1 = hp; }
+                    if (bd1 >= dist.y) { bd1 = dist.y; bi1 = j; pos1 = half1(hp); }
                 }
             }
         }
@@ -369,7 +390,7 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
             const f2 A = { sphere_area(r.x), sphere_area(r.y) };
             const v3 P = ld3(f.lcol[k]);                                     // lightColor / samples (:296), divided on the host
             const v3p rd = normalize3p(sub3p(Lp, pos));
-            const v3p B = V3P(splat2(P.x) / A, splat2(P.y) / A, splat2(P.z) / A);
+            const v3p B = V3P(div2(splat2(P.x), A), div2(splat2(P.y), A), div2(splat2(P.z), A));
             const f2 dn = dot3p(rd, nDir);
             const f2 mx = { (dn.x < 0.0f) ? 0.0f : dn.x, (dn.y < 0.0f) ? 0.0f : dn.y };   // std::max(d, 0.0f)
             v3p D = scale3p(B, mx);
@@ -397,13 +418,15 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
                 maybe_hit2(td, &m0, &m1);
                 m0 = m0 && live0; m1 = m1 && live1;
                 if (m0 || m1) {
-                    v3 hp;
-                    float dist;
-                    if (m0 && exact_hit_geo(dots_half(td, 0), r0.w, tb.geo + 3 * j, L, &hp, &dist) && dist < thr.x) {
+                    v3p hp;
+                    f2 dist;
+                    bool h0, h1;
+                    exact_hit_geo2(td, r0.w, tb.geo + 3 * j, L, m0, m1, &h0, &h1, &hp, &dist);
+                    if (h0 && dist.x < thr.x) {
                         live0 = false;                                        // occluded (:313-314); any-hit is exact
                         D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f;
                     }
-                    if (m1 && exact_hit_geo(dots_half(td, 1), r0.w, tb.geo + 3 * j, L, &hp, &dist) && dist < thr.y) {
+                    if (h1 && dist.y < thr.y) {
                         live1 = false;
                         D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f;
                     }
@@ -423,7 +446,7 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
     count_tests(f, ntests);
     if (AA) {                                                                // avgColor /= realSamples^2 (:599); /1 is the identity
         const f2 q = splat2((float)(rs * rs));
-        avg = V3P(avg.x / q, avg.y / q, avg.z / q);
+        avg = V3P(div2(avg.x, q), div2(avg.y, q), div2(avg.z, q));
     }
     if (ok0) {
         const v3 c = half0(avg);

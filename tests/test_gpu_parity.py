@@ -335,6 +335,17 @@ def test_errors_are_reported_not_fatal():
         mirt.raytrace(view, DEFAULT_LIGHT)
 
 
+def test_packed_division_equals_the_compilers():
+    """div2 (csrc/mirt_math2.hpp: two IEEE divisions sharing packed multiply-adds) against `/` on the device, 2^28 random bit
+    patterns + special values, compared as bits (tools/div2check.hip, built by __graft_entry__.build())."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "div2check")
+    assert os.path.exists(exe), "tools/div2check not built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatching" in r.stdout, r.stdout + r.stderr
+
+
 # ---- the C++ host adapter (reference-shaped Draw()) ---------------------------------------------------
 
 @pytest.mark.parametrize("which", ["rt", "rtsoft", "rtaa", "rtdof", "raster", "rasterdof", "rtasync", "rasterasync"])
