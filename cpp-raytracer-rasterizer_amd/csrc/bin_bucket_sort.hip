@@ -49,10 +49,14 @@ __device__ __forceinline__ uint32_t bs_block_scan(uint32_t v, uint32_t *s_wave /
 __global__ __launch_bounds__(256) void k_bs_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                     const uint32_t *__restrict__ total_ptr, uint32_t cap, uint32_t nbuckets, int shift,
                                                     const uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ bucket_base,
-                                                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals)
+                                                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
+                                                    uint32_t *__restrict__ count_out)
 {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_wave[4];
+    // the pair count for the host (pinned, mapped memory; nullable): how the next frames size their lists -- stored from here
+    // rather than by a copy command, which would sit in the stream between the binning and the sort
+    if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = *total_ptr;
     if (*total_ptr > cap) return;                        // the list overflowed: this frame falls back (k_rt_brute_guard), nothing to sort
     uint32_t *s_base = s_dyn, *s_cnt = s_dyn + nbuckets;
     // bucket_base[b] = pairs in buckets < b: every workgroup scans the counts for itself; workgroup 0 publishes the result
@@ -172,7 +176,7 @@ uint32_t bucket_sort_buckets(uint32_t nbins) { const int s = bucket_sort_shift(n
 // for cap pairs; bucket_cnt (filled by k_bin_pairs; zero on exit), bucket_base (nbuckets + 1), cursor (zero on entry and exit).
 hipError_t bucket_sort_pairs(const uint32_t *keys, const uint32_t *vals, const uint32_t *total_ptr, uint32_t cap, uint32_t expected,
                              uint32_t nbins, uint32_t *tmp_keys, uint32_t *tmp_vals, uint32_t *bucket_cnt, uint32_t *bucket_base,
-                             uint32_t *cursor, uint32_t *bin_off, uint32_t *entries, int cu_count, hipStream_t stream)
+                             uint32_t *cursor, uint32_t *bin_off, uint32_t *entries, int cu_count, hipStream_t stream, uint32_t *count_out)
 {
     const int shift = bucket_sort_shift(nbins);
     const uint32_t nbuckets = bucket_sort_buckets(nbins);
@@ -181,7 +185,7 @@ hipError_t bucket_sort_pairs(const uint32_t *keys, const uint32_t *vals, const u
     if (chunks < 1) chunks = 1;
     const uint32_t wgs = std::min<uint32_t>(chunks, (uint32_t)cu_count * 2u);
     hipLaunchKernelGGL(k_bs_scatter, dim3(wgs), dim3(256), lds, stream, keys, vals, total_ptr, cap, nbuckets, shift, bucket_cnt, bucket_base,
-                       cursor, tmp_keys, tmp_vals);
+                       cursor, tmp_keys, tmp_vals, count_out);
     hipLaunchKernelGGL(k_bs_local, dim3(nbuckets), dim3(256), 0, stream, tmp_keys, tmp_vals, total_ptr, cap, bucket_base, nbins, shift, bucket_cnt,
                        cursor, bin_off, entries);
     return hipGetLastError();

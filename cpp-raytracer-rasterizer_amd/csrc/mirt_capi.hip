@@ -462,6 +462,7 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
             if ((rc = ensure_pairs(S, want + want / 4))) return rc;
         }
     }
+    bool publish_count = false;
     for (int attempt = 0; attempt < 2; attempt++) {
         // MIRT_TEST_PAIR_CAP (tests only): a guessed list pretends to be this small, so that the overflow path runs
         static const uint32_t test_cap = [] { const char *e = getenv("MIRT_TEST_PAIR_CAP"); long v = e ? atol(e) : 0; return v > 0 ? (uint32_t)v : 0u; }();
@@ -480,9 +481,13 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
                 HIP_TRY(hipEventCreateWithFlags(&S.ev_count, hipEventDisableTiming));
             }
             if (!S.count_pending) {
-                HIP_TRY(hipMemcpyAsync(S.h_count, counter, 4, hipMemcpyDeviceToHost, g.stream));
-                HIP_TRY(hipEventRecord(S.ev_count, g.stream));
-                S.count_pending = true;
+                if (bucket_sort) {
+                    publish_count = true;                    // k_bs_scatter stores the count into the pinned word (below)
+                } else {
+                    HIP_TRY(hipMemcpyAsync(S.h_count, counter, 4, hipMemcpyDeviceToHost, g.stream));
+                    HIP_TRY(hipEventRecord(S.ev_count, g.stream));
+                    S.count_pending = true;
+                }
             }
             *npairs = S.known_pairs;
             break;
@@ -507,9 +512,15 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     }
 #endif
     if (bucket_sort) {
+        uint32_t *count_out = nullptr;
+        if (publish_count) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&count_out), S.h_count, 0));
         HIP_TRY(bucket_sort_pairs(S.d_pair_keys, S.d_pair_vals, counter, S.cap_used, *npairs, bs.nbins, S.d_sorted_keys, S.d_tmp_vals,
-                                  bcnt, bbase, bcur, bin_off, S.d_entries, g.cu_count, g.stream));
+                                  bcnt, bbase, bcur, bin_off, S.d_entries, g.cu_count, g.stream, count_out));
         S.bucket_dirty = false;                              // k_bs_local leaves the counts and cursors zero
+        if (publish_count) {
+            HIP_TRY(hipEventRecord(S.ev_count, g.stream));
+            S.count_pending = true;
+        }
         return MIRT_OK;
     }
     HIP_TRY(bin_sort_pairs(S.d_sort_temp, S.sort_temp_bytes, S.d_pair_keys, S.d_sorted_keys, S.d_pair_vals, S.d_entries, *npairs, key_bits_for(bs.nbins), g.stream));
