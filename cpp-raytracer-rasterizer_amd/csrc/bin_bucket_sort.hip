@@ -168,6 +168,9 @@ int bucket_sort_shift(uint32_t nbins)
     static const int min_shift = [] { const char *e = getenv("MIRT_BS_SHIFT"); int v = e ? atoi(e) : 0; return (v >= 4 && v <= 10) ? v : 8; }();
     int shift = min_shift;
     while (shift < 10 && ((nbins + 1u + (1u << shift) - 1u) >> shift) > 8192u) shift++;
+    // few bins (the 64 x 64 light cube of a moving light: 24 576): smaller buckets, so that k_bs_local has a workgroup per CU
+    // and no bucket holds tens of thousands of pairs (one workgroup places a bucket's pairs: 63 -> 20 us on the 100 k soup)
+    while (shift > 4 && ((nbins + 1u + (1u << shift) - 1u) >> shift) < 512u) shift--;
     return shift;
 }
 uint32_t bucket_sort_buckets(uint32_t nbins) { const int s = bucket_sort_shift(nbins); return (nbins + 1u + (1u << s) - 1u) >> s; }
