@@ -14,7 +14,7 @@ mirt.init(0)
 W, H = 1920, 1080
 tris = mirt.scene_soup(1, 100000, 0.05)
 mirt.scene_upload(tris)
-out = DeviceArray((H, W), np.uint32, 0)
+outs = [DeviceArray((H, W), np.uint32, 0), DeviceArray((H, W), np.uint32, 0)]
 ind = (0.5, 0.5, 0.5)
 views = [mirt.make_view((0, 0, -2.0), mirt.rot_from_yaw(0.001 * i, 1.0), float(H), W, H) for i in range(64)]
 lights = [np.array([[0.0 + 0.001 * i, -0.5, -0.7, 1, 1, 1, 14]], np.float32) for i in range(64)]
@@ -22,11 +22,11 @@ lights = [np.array([[0.0 + 0.001 * i, -0.5, -0.7, 1, 1, 1, 14]], np.float32) for
 
 def run(move_cam, move_light, frames=300):
     for i in range(8):
-        mirt.raytrace_device(views[i % 64 if move_cam else 0], lights[i % 64 if move_light else 0], ind, mirt.RT_BINNED, 0, H, 0, out.ptr, W * 4)
+        mirt.raytrace_device(views[i % 64 if move_cam else 0], lights[i % 64 if move_light else 0], ind, mirt.RT_BINNED, 0, H, 0, outs[i & 1].ptr, W * 4)
     mirt.sync()
     t0 = time.perf_counter()
     for i in range(frames):
-        mirt.raytrace_device(views[i % 64 if move_cam else 0], lights[i % 64 if move_light else 0], ind, mirt.RT_BINNED, 0, H, 0, out.ptr, W * 4)
+        mirt.raytrace_device(views[i % 64 if move_cam else 0], lights[i % 64 if move_light else 0], ind, mirt.RT_BINNED, 0, H, 0, outs[i & 1].ptr, W * 4)
     mirt.sync()
     return (time.perf_counter() - t0) / frames * 1e3
 
@@ -34,6 +34,8 @@ def run(move_cam, move_light, frames=300):
 cases = ((False, False), (True, False), (False, True), (True, True))
 if len(sys.argv) > 1:                        # "light": only the moving-light case (for a profiler run)
     cases = ((False, True),)
-for mc, ml in cases:
-    print("camera %-6s light %-6s  %.4f ms per frame" % ("moves" if mc else "fixed", "moves" if ml else "fixed", run(mc, ml)), flush=True)
+for in_flight in (1, 2):
+    mirt.set_frames_in_flight(in_flight)
+    for mc, ml in cases:
+        print("%d in flight: camera %-6s light %-6s  %.4f ms per frame" % (in_flight, "moves" if mc else "fixed", "moves" if ml else "fixed", run(mc, ml)), flush=True)
 mirt.shutdown()
