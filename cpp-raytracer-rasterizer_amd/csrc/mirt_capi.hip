@@ -424,7 +424,7 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
         if ((rc = ensure_pairs(S, initial))) return rc;
     }
-    // workgroups striding over the (256-triangle chunk, frame) work items: 8 per CU (36 KiB of LDS each, 4 resident; 1 M
+    // workgroups striding over the (256-triangle chunk, frame) work items: 8 per CU (52 KiB of LDS and 512 threads each, 3 resident; 1 M
     // triangles at 8K: 4.06 -> 3.53 ms per frame against 3 per CU); MIRT_BIN_WGS overrides
     static const int bin_wgs = [] { const char *e = getenv("MIRT_BIN_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 16) ? v : 8; }();
     static const int chunk_env = [] { const char *e = getenv("MIRT_BIN_CHUNK"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();

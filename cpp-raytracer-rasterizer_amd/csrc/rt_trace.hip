@@ -20,7 +20,7 @@
 //                  primary rays, a plain flag store for shadow rays (any-hit is exact, SURVEY A-5).
 //
 // Shadow rays read EXPANDED rows: the light-cube bins only depend on the scene and the light, so they are built once per
-// (scene, lights) -- not per frame -- and stored bin-major as 96-byte {origin row, geometry row} records.  A lane walks
+// (scene, lights) -- not per frame -- and stored bin-major as 48-byte origin rows with the triangle index in r2.w.  A lane walks
 // its bin sequentially (lanes of one bin share every address), the next row is requested while the current one is
 // tested, and nothing in the loop depends on an index load.
 //
