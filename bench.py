@@ -95,6 +95,18 @@ def measured_valu_instructions(workload, kernel_prefix):
     return None
 
 
+def measured_valu_per_frame(workload):
+    """VALU instructions of ALL per-frame kernels of the workload (every kernel the PMC pass saw more than twice: the
+    per-scene table builders run once), per frame, from the same committed pass; or None."""
+    doc = committed_profile("%s_pmc_issue.json" % ROUND)
+    ks = (doc or {}).get("workloads", {}).get(workload, {})
+    per_frame = [v for v in ks.values() if "SQ_INSTS_VALU" in v and v.get("launches", 0) > 2]
+    if not per_frame:
+        return None
+    most = max(v["launches"] for v in per_frame)
+    return sum(float(v["SQ_INSTS_VALU"]) * v["launches"] / most for v in per_frame)
+
+
 def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, samples=1, jitter=None, aa=1):
     """The oracle (CPU restatement, oracle/mirt_oracle.c) timed on this host's cores on a bounded sample of
     the same workload.  Test infrastructure: measured as a baseline, never used by the product path."""
@@ -499,6 +511,13 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                                  "lane_slots_per_test": round(insts * 64.0 / max(tests_rank, 1.0), 1),
                                                  "lane_slots_per_candidate": round(insts * 64.0 / max(float(st["candidates"]), 1.0), 1),
                                                  "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}
+                # ... and of the whole frame: launches of consecutive frames overlap (frames in flight), so what the chip's vector
+                # pipes did per frame is every per-frame kernel's instructions over the FRAME time -- the roofline of the loop
+                per_frame = measured_valu_per_frame(name)
+                if per_frame:
+                    fipc = per_frame / (ms_frame * 1e-3 * 2.4e9 * 1024)
+                    out["roofline"]["valu_issue"]["frame"] = {"instructions_per_frame": int(per_frame), "achieved": round(fipc, 4), "peak": ISSUE_CEILING,
+                                                              "frac": round(fipc / ISSUE_CEILING, 4), "ms_per_frame": round(ms_frame, 5)}
             algo_bytes = 4.0 * W * (y1 - y0) + 60.0 * len(tris)
             if kt > 0:
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": round(algo_bytes / (kt * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,

@@ -14,6 +14,8 @@ if [ "$stage" = pmc ]; then
     python tools/pmc_summary.py gpurun_out/pmc_$t > gpurun_out/pmc_$t/summary.json
     tools/pmc_valu.sh $t --workload $t --steps 10 --warmup 2 > gpurun_out/pmcv_$t.txt 2>&1
     python tools/pmc_issue_summary.py gpurun_out/pmcv_$t > gpurun_out/pmcv_$t/summary.json; echo "pmc $t rc=$?"
+    # the per-dispatch tables are tens of MiB per pass (gpurun merges at most 64 MiB back): the summaries are what is kept
+    find gpurun_out/prof_$t gpurun_out/pmc_$t gpurun_out/pmcv_$t -name "*counter_collection.csv" -delete -o -name "*kernel_trace.csv" -delete
   done
   tools/ubench > gpurun_out/ubench.txt 2>&1
   tools/edgebench > gpurun_out/edgebench.txt 2>&1
