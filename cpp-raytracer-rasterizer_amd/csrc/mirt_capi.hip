@@ -53,7 +53,7 @@ struct RtTraceFrame {
 template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
 __global__ void k_rt_brute_guard(const RtFrame, const uint32_t *, uint32_t, int, int);
 __global__ void k_geo_table(const float *, int, GeoRow *);
-__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *);
+__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t);
 size_t rt_trace_lds_bytes();
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
 __global__ void k_cull(const float *, int, const CullParams, uint8_t *);
@@ -112,6 +112,11 @@ struct RtScratch {
     uint64_t bin_key = 0;
     uint32_t bin_entries = 0;                    // pairs of the current binning
     bool bin_key_valid = false;
+    // lights that moved: this stream's own light-cube pass (rt_enqueue_binned), rows in the order of the pair list
+    LightRow *d_light_rows = nullptr;
+    uint32_t cap_light_rows = 0;
+    int last_bin_mode = -1;                      // what the last pass binned (camera alone / camera + n light cubes): a guessed
+                                                 // list size only carries over between passes of the same kind
 };
 
 // The light-cube bins of the binned ray tracer: they depend on the scene and the light positions only, not on the camera,
@@ -120,7 +125,8 @@ struct LightCache {
     bool valid = false;
     uint64_t key = 0;                            // scene version + light positions (not the grid)
     int cube_bins = 0;                           // bins per face side of the tables held
-    int stable = 0;                              // consecutive frames that found their lights in the cache
+    uint64_t track_key = 0;                      // the lights of the most recent binned frame ...
+    int stable = 0;                              // ... and for how many frames in a row they have been the same
     OriginRow *d_light_tab = nullptr;            // nl x n origin rows
     size_t cap_tab = 0;
     BinFrameDesc *d_frames = nullptr;            // 6 x nl frame descriptors
@@ -497,6 +503,7 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         HIP_TRY(hipStreamSynchronize(g.stream));
         *npairs = total;
         S.known_pairs = total; S.have_known = true;
+        S.count_pending = false;                             // (a count still on its way belongs to an earlier pass, maybe of another kind)
         if (total <= S.cap_entries) break;
         if (attempt == 1) return fail(MIRT_ERR_HIP, "binning produced %u pairs twice with room for %u", total, S.cap_entries);
         if ((rc = ensure_pairs(S, (size_t)total + total / 8 + 4096))) return rc;
@@ -528,30 +535,46 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     return MIRT_OK;
 }
 
-// The light-cube bins (six faces of B x B bins around every light position) and their expanded rows.  Built on g.stream as a
-// barrier call -- the frames of both streams read the tables -- whenever the scene, a light position or the grid changed.
-// Grid: the fine grid (`fine_bins` per face side) shortens the shadow lists but costs ~1 ms to build for 100 k triangles, the
-// coarse one (CUBE_BINS_MIN) a third of that.  The reference moves the light with keys (raytracer.cpp:152-162) as readily as the
-// camera, so lights that changed since the previous frame get the coarse grid, and the fine one is built once the same lights have
-// been seen for LIGHT_STABLE_FRAMES frames in a row (`adapt` false: always `fine_bins`).  The grid never changes a result.
-constexpr int LIGHT_STABLE_FRAMES = 4;
-int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int nlights, int fine_bins, bool adapt)
+// Key of what the light-cube bins depend on: the scene and the light positions.
+uint64_t light_key_of(const float *origins, int nlights)
+{
+    uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
+    auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
+    mix(origins + 3, sizeof(float) * 3 * nlights); mix(&nlights, 4); mix(&g.n, 4);
+    return key;
+}
+
+// Frame descriptors of the light cubes: six faces of B x B bins around every light position, bins numbered from `base`.
+void fill_light_frames(BinFrameDesc *frames, const RtFrame &f, int nlights, int cube_bins, uint32_t base)
+{
+    memset(frames, 0, sizeof(BinFrameDesc) * 6 * nlights);
+    for (int k = 0; k < nlights; k++)
+        for (int face = 0; face < 6; face++) {
+            BinFrameDesc &d = frames[k * 6 + face];
+            const int ax = face >> 1;
+            d.P0[ax] = (face & 1) ? -1.0f : 1.0f;         // negD ~ s*e_k + u*e_(k+1) + v*e_(k+2)
+            d.Pu[(ax + 1) % 3] = 1.0f;
+            d.Pv[(ax + 2) % 3] = 1.0f;
+            d.rw[ax] = d.P0[ax]; d.ru[(ax + 1) % 3] = 1.0f; d.rv[(ax + 2) % 3] = 1.0f;   // g = m*(s e_k + u e_k1 + v e_k2)
+            memcpy(d.S, f.lpos[k], 12);                       // light position k (jittered sample with soft shadows)
+            d.dmax = 2.0f;
+            d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / (float)cube_bins; d.dv = 2.0f / (float)cube_bins;
+            d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
+            d.nbu = cube_bins; d.nbv = cube_bins; d.j0 = 0; d.j1 = cube_bins;
+            d.base = base; d.tab = 1 + k;
+            base += (uint32_t)(cube_bins * cube_bins);
+        }
+}
+
+// The SHARED light-cube bins and their expanded rows, for lights that stand still: built on g.stream as a barrier call -- the
+// frames of both streams read the tables -- whenever the scene, a light position or the grid differs from what is held.  (Lights
+// that just moved do not come here: rt_enqueue_binned bins their cubes together with the camera frame, on the frame's own stream.)
+int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int nlights, int cube_bins)
 {
     int rc;
     LightCache &C = g.lc;
-    uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
-    {
-        auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
-        mix(origins + 3, sizeof(float) * 3 * nlights); mix(&nlights, 4); mix(&g.n, 4);
-    }
-    int cube_bins = fine_bins;
-    if (C.valid && C.key == key) {
-        C.stable++;
-        if (C.cube_bins == fine_bins || (adapt && C.stable < LIGHT_STABLE_FRAMES)) return MIRT_OK;      // keep the tables held
-    } else {
-        C.stable = 0;
-        if (adapt) cube_bins = std::min(fine_bins, CUBE_BINS_MIN);
-    }
+    const uint64_t key = light_key_of(origins, nlights);
+    if (C.valid && C.key == key && C.cube_bins == cube_bins) return MIRT_OK;
     C.valid = false;
     const int other = (g.stream == g.streams[0]) ? 1 : 0;
     if (g.in_flight == 2) {                                  // frames of the other stream may still read the old tables
@@ -576,24 +599,7 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
     C.nrows = 0;
     if (nlights > 0) {
         BinFrameDesc frames[6 * MIRT_MAX_LIGHTS];
-        memset(frames, 0, sizeof frames);
-        uint32_t base = 0;
-        for (int k = 0; k < nlights; k++)
-            for (int face = 0; face < 6; face++) {
-                BinFrameDesc &d = frames[k * 6 + face];
-                const int ax = face >> 1;
-                d.P0[ax] = (face & 1) ? -1.0f : 1.0f;         // negD ~ s*e_k + u*e_(k+1) + v*e_(k+2)
-                d.Pu[(ax + 1) % 3] = 1.0f;
-                d.Pv[(ax + 2) % 3] = 1.0f;
-                d.rw[ax] = d.P0[ax]; d.ru[(ax + 1) % 3] = 1.0f; d.rv[(ax + 2) % 3] = 1.0f;   // g = m*(s e_k + u e_k1 + v e_k2)
-                memcpy(d.S, f.lpos[k], 12);                       // light position k (jittered sample with soft shadows)
-                d.dmax = 2.0f;
-                d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / (float)cube_bins; d.dv = 2.0f / (float)cube_bins;
-                d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
-                d.nbu = cube_bins; d.nbv = cube_bins; d.j0 = 0; d.j1 = cube_bins;
-                d.base = base; d.tab = 1 + k;
-                base += (uint32_t)(cube_bins * cube_bins);
-            }
+        fill_light_frames(frames, f, nlights, cube_bins, 0u);
         HIP_TRY(hipMemcpyAsync(C.d_frames, frames, sizeof(BinFrameDesc) * 6 * nlights, hipMemcpyHostToDevice, g.stream));
         HIP_TRY(hipMemcpyAsync(C.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
         hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, nlights), dim3(256), 0, g.stream,
@@ -612,9 +618,10 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
         C.nrows = npairs;
         if (npairs)
             hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((npairs + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.n, C.d_rows);
+                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.n, C.d_rows, (const uint32_t *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
         S.bin_key_valid = false;                             // the stream's pair list now holds the light pass
+        S.last_bin_mode = -1;
     } else {
         HIP_TRY(hipMemsetAsync(C.d_off, 0, 4, g.stream));
     }
@@ -628,23 +635,35 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
     return MIRT_OK;
 }
 
-// A binned frame: camera origin rows, camera-tile bins (the only per-frame binning), trace.
+// A binned frame: camera origin rows, camera-tile bins, trace.  The light-cube bins come from the shared cache when the lights
+// stand still -- the only per-frame binning is then the camera's -- or, for lights that moved within the last
+// LIGHT_STABLE_FRAMES frames, from this frame's own pass: their cubes (CUBE_BINS_MIN bins per side) are binned TOGETHER with the
+// camera frame into the stream's pair list and expanded into the stream's rows.  Nothing of that is shared, so a moving light
+// needs no barrier between the streams and no host sync (the list is sized like the camera's: from an earlier frame's count).
+// The reference moves the light with keys as readily as the camera (raytracer.cpp:152-162).
+constexpr int LIGHT_STABLE_FRAMES = 4;
 int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const float *origins, int nlights, int y0, int y1)
 {
     int rc;
     g.stats.mode_used = MIRT_RT_BINNED;
-    // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists; the bins are built once per (scene,
-    // lights), not per frame, so what they cost is memory (48 bytes per (bin, triangle) pair) and the build when a light
-    // moves (light_cache_ensure picks the coarse grid for lights that just moved).  Measured on the 100 k soup at 1080p (trace
-    // kernel): 64: 153 us, 128: 125 us, 256: 105 us.  MIRT_CUBE_BINS=64|128|256 fixes the grid.
+    // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists; the shared bins are built once per
+    // (scene, lights), not per frame, so what they cost is memory (48 bytes per (bin, triangle) pair) and ~1 ms of build for
+    // 100 k triangles.  Measured on the 100 k soup at 1080p (trace kernel): 64: 153 us, 128: 125 us, 256: 105 us.
+    // MIRT_CUBE_BINS=64|128|256 fixes the grid (and keeps every frame on the shared cache).
     static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
     int fine_bins = g.n < 2000 ? CUBE_BINS_MIN : (g.n < 20000 ? 2 * CUBE_BINS_MIN : 4 * CUBE_BINS_MIN);
     const bool fixed_grid = cube_override == 64 || cube_override == 128 || cube_override == 256;
     if (fixed_grid) fine_bins = cube_override;
 
+    const uint64_t lkey = light_key_of(origins, nlights);
+    if (g.lc.track_key == lkey) g.lc.stable++;
+    else { g.lc.track_key = lkey; g.lc.stable = 0; }
+    const bool cached = g.lc.valid && g.lc.key == lkey && g.lc.cube_bins == fine_bins;
+    const bool transient = nlights > 0 && !fixed_grid && !cached && g.lc.stable < LIGHT_STABLE_FRAMES;
+
     k_begin(MIRT_K_BIN);
-    if ((rc = light_cache_ensure(S, f, origins, nlights, fine_bins, !fixed_grid))) return rc;
-    const int cube_bins = g.lc.cube_bins;
+    if (!transient && (rc = light_cache_ensure(S, f, origins, nlights, fine_bins))) return rc;
+    const int cube_bins = transient ? CUBE_BINS_MIN : fine_bins;
 
     BinSet bs;
     memset(&bs, 0, sizeof bs);
@@ -669,7 +688,9 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         bs.frame0.shell_d0 = (float)dn;
         bs.frame0.shell_iw = okr ? (float)(ns / (df - dn)) : 0.0f;
     }
-    bs.nbins = (uint32_t)bs.frame0.nbu * bs.frame0.nbv * (uint32_t)bs.frame0.nshell;
+    const uint32_t cam_keys = (uint32_t)bs.frame0.nbu * bs.frame0.nbv * (uint32_t)bs.frame0.nshell;
+    const uint32_t per_light = 6u * (uint32_t)(cube_bins * cube_bins);
+    bs.nbins = cam_keys + (transient ? per_light * (uint32_t)nlights : 0u);
     if (bs.nbins + 1 > S.cap_bins) {
         const size_t cap = (size_t)bs.nbins + 1;
         if ((rc = dev_realloc(&S.d_bin_off, cap))) { S.cap_bins = 0; return rc; }
@@ -683,17 +704,55 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     {
         auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
         mix(view, sizeof *view); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4); mix(&g.aa, 4);
+        if (transient) { mix(&lkey, 8); mix(&cube_bins, 4); }
     }
-    // first kernel of the frame: the camera's origin rows; it also zeroes the hit counters and the pair counter
+    const int bin_mode = transient ? 1 + nlights : 0;
     g.hits_clean[g.hits_cur] = false;
-    hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1), dim3(256), 0, g.stream,
-                       g.d_tris, g.n, (const float *)nullptr, V3(origins[0], origins[1], origins[2]), 0, S.d_cam_tab, (OriginRow *)nullptr,
-                       (uint32_t *)nullptr, g.d_hits, S.d_bin_counters);
-    // the pair count is read back (4 bytes + one sync of this stream) only when the inputs that determine it changed
+    if (transient) {
+        // this stream's own light tables: origin rows per light, the cubes' frame descriptors behind the camera's, the rows
+        if (nlights > S.light_tab_lights || S.light_tab_n != g.n) {
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            S.light_tab_lights = 0;
+            if ((rc = dev_realloc(&S.d_light_tab, (size_t)nlights * g.n))) return rc;
+            S.light_tab_lights = nlights;
+            S.light_tab_n = g.n;
+        }
+        if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * (1 + 6 * MIRT_MAX_LIGHTS)));
+        static thread_local BinFrameDesc frames[1 + 6 * MIRT_MAX_LIGHTS];
+        frames[0] = bs.frame0;
+        fill_light_frames(frames + 1, f, nlights, cube_bins, cam_keys);
+        HIP_TRY(hipMemcpyAsync(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
+        bs.frames = S.d_frames; bs.nframes = 1 + 6 * nlights;
+        // first kernel of the frame: origin rows of the camera and of every light; it also zeroes the hit and pair counters
+        hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1 + nlights), dim3(256), 0, g.stream,
+                           g.d_tris, g.n, S.d_origins, V3(0.0f, 0.0f, 0.0f), 0, S.d_cam_tab, S.d_light_tab,
+                           (uint32_t *)nullptr, g.d_hits, S.d_bin_counters);
+    } else {
+        // first kernel of the frame: the camera's origin rows; it also zeroes the hit counters and the pair counter
+        hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1), dim3(256), 0, g.stream,
+                           g.d_tris, g.n, (const float *)nullptr, V3(origins[0], origins[1], origins[2]), 0, S.d_cam_tab, (OriginRow *)nullptr,
+                           (uint32_t *)nullptr, g.d_hits, S.d_bin_counters);
+    }
+    // the pair count is read back (4 bytes + one sync of this stream) only when the inputs that determine it changed AND no
+    // count of an earlier pass of the same kind is at hand (a camera-only count says nothing about camera + light cubes)
     const bool fresh = !S.bin_key_valid || S.bin_key != key;
-    if ((rc = bin_pass(S, bs, S.d_cam_tab, nullptr, S.d_bin_counters, S.d_bin_off, fresh, &S.bin_entries, true))) return rc;
+    const bool may_guess = S.last_bin_mode == bin_mode;
+    if ((rc = bin_pass(S, bs, S.d_cam_tab, transient ? S.d_light_tab : nullptr, S.d_bin_counters, S.d_bin_off, fresh, &S.bin_entries, may_guess))) return rc;
+    S.last_bin_mode = bin_mode;
     S.bin_key = key;
     S.bin_key_valid = true;
+    if (transient) {
+        if (S.cap_light_rows < S.cap_entries) {              // one row per pair at most; grown with the pair list (rare)
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            S.cap_light_rows = 0;
+            if ((rc = dev_realloc(&S.d_light_rows, (size_t)S.cap_entries))) return rc;
+            S.cap_light_rows = S.cap_entries;
+        }
+        const uint32_t expect = std::max<uint32_t>(S.bin_entries, 1u);
+        hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
+                           S.d_bin_off + cam_keys, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used);
+    }
     k_end(MIRT_K_BIN);
 
     RtTraceFrame tf;
@@ -702,8 +761,8 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.cam_off = S.d_bin_off;
     tf.cam_entries = S.d_entries;
     tf.geo = g.d_geo;
-    tf.light_off = g.lc.d_off;
-    tf.light_rows = g.lc.d_rows;
+    tf.light_off = transient ? S.d_bin_off + cam_keys : g.lc.d_off;
+    tf.light_rows = transient ? S.d_light_rows : g.lc.d_rows;
     tf.tiles_x = bs.frame0.nbu;
     tf.cube_bins = cube_bins;
     tf.cam_shells = bs.frame0.nshell;
@@ -719,7 +778,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         // the safety net of a pair list sized without a read-back (bin_pass): leaves at once unless the list overflowed
         RtFrame bf = f;
         bf.cam_tab = S.d_cam_tab;
-        bf.light_tab = g.lc.d_light_tab;
+        bf.light_tab = transient ? S.d_light_tab : g.lc.d_light_tab;
         bf.unsafe = nullptr;
         const int rows = y1 - y0, nbx = (view->width + 127) / 128, nby = (rows + 3) / 4;
         hipLaunchKernelGGL(k_rt_brute_guard, dim3((unsigned)std::min<long long>((long long)nbx * nby, (long long)g.cu_count * 4)), dim3(256), 0, g.stream,
@@ -1100,7 +1159,7 @@ extern "C" void mirt_shutdown(void)
     (void)hipSetDevice(g.device);
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
     for (RtScratch &S : g.rt)
-        for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_bin_off,
+        for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_light_rows, (void *)S.d_bin_off,
                          (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp, (void *)S.d_tmp_vals, (void *)S.d_bucket })
             if (p) (void)hipFree(p);
     for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }

@@ -49,15 +49,18 @@ __global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tri
 }
 
 // rows[p] = origin row of triangle entries[p] for the light its bin belongs to, with the triangle index in r2.w: the sorted
-// pair list of the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.
-// bin_off[k * bins_per_light] is where the pairs of light k start.
+// pair list of the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.  bin_off points at the
+// first light bin (the pairs of bins in front of it -- a camera frame binned in the same pass -- are not light pairs);
+// bin_off[k * bins_per_light] is where the pairs of light k start.  pair_count / pair_cap (nullable): the pass that sized its
+// list from an earlier frame's count leaves its tables untouched when the list overflowed -- nothing to expand then.
 __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ entries,
                                                            int nlights, uint32_t bins_per_light,
                                                            const OriginRow *__restrict__ light_tab, int n,
-                                                           LightRow *__restrict__ rows)
+                                                           LightRow *__restrict__ rows, const uint32_t *__restrict__ pair_count, uint32_t pair_cap)
 {
-    const uint32_t total = bin_off[(size_t)nlights * bins_per_light];
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+    if (pair_count && *pair_count > pair_cap) return;
+    const uint32_t first = bin_off[0], total = bin_off[(size_t)nlights * bins_per_light];
+    for (uint32_t p = first + blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
         int k = 0;
         while (k + 1 < nlights && bin_off[(size_t)(k + 1) * bins_per_light] <= p) k++;
         const uint32_t tri = entries[p];
