@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
         v3 P = div3s(p3, zinv);                                       // pPos3d /= p.zinv (:557)
         P = vec_mul_mat3(P, f.invrot);                                // * glm::inverse(cameraRot) (:559)
         P = add3(P, ld3(f.cam));                                      // += cameraPos (:560)
-        fdist = distance3(P, ld3(f.cam)) - f.focal_plane;             // focalDistances (:563-565)
+        if (f.fd) fdist = distance3(P, ld3(f.cam)) - f.focal_plane;   // focalDistances (:563-565): only the depth-of-field pass reads them
         v3 result = V3(0.0f, 0.0f, 0.0f);
         for (int k = 0; k < f.nlights; k++) {
             const v3 L = ld3(f.lpos[k]);
