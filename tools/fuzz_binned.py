@@ -1,4 +1,4 @@
-"""tools/fuzz_binned.py [first_seed count] -- (GPU box) binned vs brute-force frames on many seeded random configurations
+"""tools/fuzz_binned.py [first_seed count [frames]] -- (GPU box) binned vs brute-force frames on many seeded random configurations
 (scene size and triangle size, cameras inside / outside, up to four lights some of them grazing a triangle's plane or
 sitting on a vertex, soft shadows, supersampling, bands).  Prints every mismatch; exit code 1 if there was one."""
 import sys
@@ -10,6 +10,9 @@ import mirt
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+# frames per configuration: the first four of a light position bin its cube themselves, the fifth builds the shared fine cube,
+# the sixth reads it from the cache -- 6 covers all three paths (1: the first only)
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 mirt.init(0)
 bad = 0
 for seed in range(first, first + count):
@@ -49,8 +52,11 @@ for seed in range(first, first + count):
     try:
         mirt.scene_upload(tris)
         view = mirt.make_view(cam, rot, focal, W, H)
-        a = mirt.raytrace(view, lights, mode=mirt.RT_BINNED)
         b = mirt.raytrace(view, lights, mode=mirt.RT_BRUTE)
+        for rep in range(frames):
+            a = mirt.raytrace(view, lights, mode=mirt.RT_BINNED)
+            if not (np.array_equal(a["index"], b["index"]) and np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32)) and np.array_equal(a["xrgb"], b["xrgb"])):
+                break
     finally:
         mirt.set_soft_shadows(1)
         mirt.set_antialiasing(1)
@@ -59,5 +65,5 @@ for seed in range(first, first + count):
         bad += 1
         print("MISMATCH seed", seed, "n", len(tris), "size", size, "WxH", W, H, "lights", nl, "mode", mode, "samples", samples, "aa", aa,
               "index diffs", int((a["index"] != b["index"]).sum()), "word diffs", int((a["xrgb"] != b["xrgb"]).sum()), flush=True)
-print("fuzz: %d configurations from seed %d, %d mismatches" % (count, first, bad))
+print("fuzz: %d configurations from seed %d, %d frame(s) each, %d mismatches" % (count, first, frames, bad))
 sys.exit(1 if bad else 0)
