@@ -409,18 +409,41 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
 
     # per-kernel durations of this rank IN THE SAME MODE as the timed loop (same frames in flight, same moving camera):
     # the library brackets every launch with hipEvents on the stream it runs on
+    # -- with two frames in flight the frame measured is the one BEFORE the last of a run of frames queued back to back
+    # (mirt_get_previous_kernel_ms): its kernels ran between the frames on both sides of it, as every frame of the timed loop
+    # does; the last frame of a run drains alone and would read like a single-stream launch.
     mirt.set_profiling(True)
     kacc, kn = {}, 0
-    for i in range(min(steps * fps_step, 64)):
-        frame()
-        mirt.sync()
-        for k, v in mirt.stats()["kernel_ms"].items():
+    overlapped = in_flight == 2 and not native and batch == 1
+    for i in range(max(4, min(steps * fps_step, 64) // 4)):
+        for _ in range(6 if overlapped else 1):
+            frame()
+        if overlapped:
+            kms, _ = mirt.previous_kernel_ms()
+        else:
+            mirt.sync()
+            kms = mirt.stats()["kernel_ms"]
+        for k, v in kms.items():
             kacc[k] = kacc.get(k, 0.0) + v
         kn += 1
     finish_batch()
     env.fence()
-    mirt.set_profiling(False)
     kernel_ms = {k: v / kn for k, v in kacc.items() if v > 0}
+    # ... and the same launches ALONE on the device (a sync after every frame): what the kernel takes when nothing shares the
+    # chip with it -- beside the line's figures, never in them
+    kernel_ms_alone = None
+    if overlapped:
+        aacc, an = {}, 0
+        for i in range(12):
+            frame()
+            mirt.sync()
+            for k, v in mirt.stats()["kernel_ms"].items():
+                aacc[k] = aacc.get(k, 0.0) + v
+            an += 1
+        finish_batch()
+        env.fence()
+        kernel_ms_alone = {k: v / an for k, v in aacc.items() if v > 0}
+    mirt.set_profiling(False)
 
     static = None
     if extras and moving and world == 1:
@@ -469,6 +492,8 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
             "camera": ("orbit: yaw += %g rad per frame, %d views" % (ORBIT_STEP, nviews)) if moving else "static",
             "kernel_ms_rank0": {k: round(v, 5) for k, v in kernel_ms.items()},
         }
+        if kernel_ms_alone:
+            out["kernel_ms_alone_rank0"] = {k: round(v, 5) for k, v in kernel_ms_alone.items()}
         if static:
             out["static_camera"] = static
         if host:
@@ -500,7 +525,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                "traffic": measured_traffic(name, [kname]) if world == 1 else None,
                                "traffic_source": "profiles/%s_hbm_traffic.json (rocprofv3 PMC, bytes per launch)" % ROUND,
                                "tests_per_launch": int(tests_rank), "candidates_per_launch": int(st["candidates"]), "kernel_ms": round(kt, 5),
-                               "kernel_ms_mode": "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera" % (in_flight, "moving" if moving else "static"),
+                               "kernel_ms_mode": "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera%s" % (in_flight, "moving" if moving else "static", "; the frame before the last of 6 queued back to back (overlapped on both sides)" if overlapped else ""),
                                "reference_tests_per_launch": int(rays_rank * len(tris)),
                                "reference_equivalent_tflops": None if kt <= 0 else round(rays_rank * len(tris) * FLOP_PER_TEST / (kt * 1e-3) / 1e12, 3),
                                "note": "FP32 VALU-bound: not a contraction, so no MFMA; peak counts an FMA as 2 flop but bit-exact "
@@ -508,6 +533,14 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                        "launch EXECUTED x 60 flop (candidates skipped by binning, depth order or the near bound do not "
                                        "count); reference_equivalent = the brute-force work of the reference (rays x triangles x 60) "
                                        "over the same time"}
+            # launches of consecutive frames overlap, so a launch's own duration understates what the chip does: the same work over
+            # the FRAME time, and the launch alone on the device, beside it
+            fach = tests_rank * FLOP_PER_TEST / (ms_frame * 1e-3) / 1e12
+            out["roofline"]["frame"] = {"achieved": round(fach, 3), "frac": round(fach / PEAK_FP32_TFLOPS, 4), "ms_per_frame": round(ms_frame, 5)}
+            if kernel_ms_alone and kernel_ms_alone.get("trace", 0.0) > 0:
+                ka = kernel_ms_alone["trace"]
+                out["roofline"]["alone"] = {"kernel_ms": round(ka, 5), "achieved": round(tests_rank * FLOP_PER_TEST / (ka * 1e-3) / 1e12, 3),
+                                            "frac": round(tests_rank * FLOP_PER_TEST / (ka * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)}
             insts = measured_valu_instructions(name, kname) if world == 1 else None
             if insts and kt > 0:
                 # issue-slot view of the same kernel: VALU instructions per launch (profiled) over the live duration, per SIMD
@@ -553,7 +586,11 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                    "traffic": measured_traffic(name, ["k_raster_resolve"]) if world == 1 else None,
                                    "traffic_source": "profiles/%s_hbm_traffic.json (rocprofv3 PMC, bytes per launch)" % ROUND,
                                    "algorithmic_bytes": int(rb), "kernel_ms": round(tr, 5),
-                                   "kernel_ms_mode": "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera" % (in_flight, "moving" if moving else "static"),
+                                   "alone": (None if not (kernel_ms_alone and kernel_ms_alone.get("raster_resolve", 0.0) > 0) else
+                                             {"kernel_ms": round(kernel_ms_alone["raster_resolve"], 5),
+                                              "achieved": round(rb / (kernel_ms_alone["raster_resolve"] * 1e-3) / 1e9, 3),
+                                              "frac": round(rb / (kernel_ms_alone["raster_resolve"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)}),
+                                   "kernel_ms_mode": "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera%s" % (in_flight, "moving" if moving else "static", "; the frame before the last of 6 queued back to back (overlapped on both sides)" if overlapped else ""),
                                    "note": "12 B per pixel (8 B key read + 4 B XRGB write) + 8 B per covered pixel (key re-zeroed)"}
             # The whole frame: fragments x 8 + resolve (above), over the frame time of the timed loop (frames
             # overlap: the latency-bound setup of one hides behind the HBM kernels of the other)
@@ -683,7 +720,7 @@ def main():
             r = run_workload(env, sub, max(4, steps // 2), 1, "auto", not args.static_camera, not args.no_cpu_baseline and sub != "soup1m8k", target_s=0.07, extras=False)
             if r is not None:
                 subs[sub] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_frame", "frames_per_s", "frames_per_step", "steps", "timed_region_s",
-                                               "kernel_ms_rank0", "config", "roofline", "_cpu_leg") if k in r}
+                                               "kernel_ms_rank0", "kernel_ms_alone_rank0", "config", "roofline", "_cpu_leg") if k in r}
         if out is not None:
             out["sub_results"] = subs
     # the CPU legs, after all GPU timing

@@ -151,8 +151,14 @@ struct Ctx {
     bool last_self_contained = false;            // ... and whether that call may overlap its neighbours
     hipEvent_t ev_chain = nullptr;               // orders a call after the previous one when it must not overlap it
     hipEvent_t ev_cull = nullptr;                // orders the frames of the other stream after mirt_cull_device
-    hipEvent_t ev[EV_COUNT] = {};
-    bool ev_used[8] = {};
+    // profiling events: one set per stream, so that the times of a frame survive the frame that follows it on the other stream
+    // (mirt_get_previous_kernel_ms: the frame before the last one overlapped its neighbours on both sides)
+    hipEvent_t ev_sets[2][EV_COUNT] = {};
+    bool ev_used_sets[2][8] = {};
+    bool call_timed_sets[2] = { false, false };
+    int ev_cur = 0;                              // the set of the current / most recent call
+    hipEvent_t *ev = ev_sets[0];
+    bool *ev_used = ev_used_sets[0];
 
     // scene
     int n = 0;
@@ -322,10 +328,14 @@ void call_begin(bool self_contained = false)
     (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (torch polls events:
                                                  // hipErrorNotReady) so that the launch checks below report our own launches only
     memset(&g.stats, 0, sizeof g.stats);
-    memset(g.ev_used, 0, sizeof g.ev_used);
+    g.ev_cur = (g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0;
+    g.ev = g.ev_sets[g.ev_cur];
+    g.ev_used = g.ev_used_sets[g.ev_cur];
+    memset(g.ev_used, 0, sizeof g.ev_used_sets[0]);
     // the call's own start / end events only when profiling is on: an event record costs ~2.7 us of host time, a quarter of
     // a 500 x 500 Cornell frame (12.9 -> 7.x us per frame without the two of them)
     g.call_timed = g.profiling;
+    g.call_timed_sets[g.ev_cur] = g.call_timed;
     if (g.call_timed) (void)hipEventRecord(g.ev[EV_CALL0], g.stream);
 }
 void call_end() { if (g.call_timed) (void)hipEventRecord(g.ev[EV_CALL1], g.stream); g.stats_stream = g.stream; g.stats_pending = true; }
@@ -1140,7 +1150,8 @@ extern "C" int mirt_init(int device)
     g.last_self_contained = false;
     HIP_TRY(hipEventCreateWithFlags(&g.ev_chain, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&g.ev_cull, hipEventDisableTiming));
-    for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev[i]));
+    for (int si = 0; si < 2; si++) for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev_sets[si][i]));
+    g.ev_cur = 0; g.ev = g.ev_sets[0]; g.ev_used = g.ev_used_sets[0];
     for (int i = 0; i < 4; i++) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits2[i]), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
         HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
@@ -1177,7 +1188,7 @@ extern "C" void mirt_shutdown(void)
     if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);
     raster_scratch_free(g.raster[0]);
     raster_scratch_free(g.raster[1]);
-    for (int i = 0; i < EV_COUNT; i++) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
+    for (int si = 0; si < 2; si++) for (int i = 0; i < EV_COUNT; i++) if (g.ev_sets[si][i]) { (void)hipEventDestroy(g.ev_sets[si][i]); g.ev_sets[si][i] = nullptr; }
     if (g.ev_chain) (void)hipEventDestroy(g.ev_chain);
     if (g.ev_cull) (void)hipEventDestroy(g.ev_cull);
     for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
@@ -1636,6 +1647,26 @@ extern "C" int mirt_get_stats(mirt_stats *out)
                                                  // behind: do not hand it to the next HIP user of this thread
     }
     *out = g.stats;
+    return MIRT_OK;
+}
+
+// Per-kernel GPU times of the call BEFORE the last one.
+extern "C" int mirt_get_previous_kernel_ms(float *kernel_ms8, float *gpu_ms)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (!kernel_ms8) return fail(MIRT_ERR_INVALID_ARGUMENT, "kernel_ms8 must not be NULL");
+    if (g.in_flight != 2) return fail(MIRT_ERR_INVALID_ARGUMENT, "the call before the last one keeps its events only with mirt_set_frames_in_flight(2)");
+    HIP_TRY(sync_all());
+    const int set = g.ev_cur ^ 1;
+    float ms = 0.0f;
+    if (gpu_ms) *gpu_ms = (g.call_timed_sets[set] && hipEventElapsedTime(&ms, g.ev_sets[set][EV_CALL0], g.ev_sets[set][EV_CALL1]) == hipSuccess) ? ms : 0.0f;
+    for (int k = 0; k < 8; k++) {
+        kernel_ms8[k] = 0.0f;
+        if (g.profiling && g.ev_used_sets[set][k] && hipEventElapsedTime(&ms, g.ev_sets[set][EV_K0 + 2 * k], g.ev_sets[set][EV_K0 + 2 * k + 1]) == hipSuccess)
+            kernel_ms8[k] = ms;
+    }
+    (void)hipGetLastError();
     return MIRT_OK;
 }
 

@@ -21,7 +21,7 @@ EXPORTS = (
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_abi_version", "mirt_set_profiling", "mirt_sync",
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
     "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
-    "mirt_rasterise_device", "mirt_get_stats", "mirt_surface_register", "mirt_surface_unregister", "mirt_raytrace_async", "mirt_rasterise_async",
+    "mirt_rasterise_device", "mirt_get_stats", "mirt_get_previous_kernel_ms", "mirt_surface_register", "mirt_surface_unregister", "mirt_raytrace_async", "mirt_rasterise_async",
     "mirt_band_of", "mirt_band_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_comm_selfcheck", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
 )
 
@@ -81,6 +81,7 @@ def load():
     lib.mirt_rasterise_device.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                           _vp, C.c_int, _vp, _vp, _vp]
     lib.mirt_get_stats.argtypes = [C.POINTER(Stats)]
+    lib.mirt_get_previous_kernel_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mirt_surface_register.argtypes = [_vp, C.c_size_t]
     lib.mirt_surface_unregister.argtypes = [_vp]
     lib.mirt_raytrace_async.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int]
@@ -154,6 +155,14 @@ def surface_register(arr):
 
 def surface_unregister(arr):
     _check(load().mirt_surface_unregister(_ptr(arr)))
+
+
+def previous_kernel_ms():
+    """kernel_ms (dict like stats()["kernel_ms"]) and gpu_ms of the call before the last one (two frames in flight, profiling on)."""
+    k = (C.c_float * 8)()
+    gms = C.c_float()
+    _check(load().mirt_get_previous_kernel_ms(k, C.byref(gms)))
+    return {name: float(k[i]) for i, name in enumerate(KERNEL_NAMES)}, float(gms.value)
 
 
 def set_profiling(on):

@@ -279,6 +279,11 @@ MIRT_API int mirt_rasterise_sharded(const mirt_view *views, int nviews, const mi
 
 /* Counters / timings of the most recent render call. */
 MIRT_API int mirt_get_stats(mirt_stats *out);
+/* With profiling on and two frames in flight: the per-kernel GPU times (kernel_ms8[8], indexed like mirt_stats.kernel_ms) and the
+ * GPU time of the call BEFORE the last one -- the frame on the other stream, whose kernels ran while the frames on both sides of
+ * it were running, which is the state a render loop is in.  (mirt_get_stats reports the last call, whose tail runs alone.)
+ * Waits for both streams. */
+MIRT_API int mirt_get_previous_kernel_ms(float *kernel_ms8, float *gpu_ms);
 
 #ifdef __cplusplus
 }

@@ -346,6 +346,36 @@ def test_packed_division_equals_the_compilers():
     assert r.returncode == 0 and " 0 mismatching" in r.stdout, r.stdout + r.stderr
 
 
+def test_profiling_events_per_stream():
+    """mirt_set_profiling: per-kernel GPU times of the last call (mirt_get_stats) and, with two frames in flight, of the call
+    before it (mirt_get_previous_kernel_ms: the events of a frame survive the frame that follows it on the other stream)."""
+    from devbuf import DeviceArray
+    tris = np.concatenate([mirt.scene_cornell(), mirt.scene_soup(5, 3000, 0.08)])
+    mirt.scene_upload(tris)
+    W, H = 640, 360
+    views = [mirt.make_view((0.01 * i, 0, -2.2), mirt.rot_from_yaw(0.0, 1.0), 180.0, W, H) for i in range(6)]
+    outs = [DeviceArray((H, W), np.uint32, 0), DeviceArray((H, W), np.uint32, 0)]
+    mirt.set_profiling(True)
+    try:
+        mirt.raytrace_device(views[0], mirt.DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, outs[0].ptr, W * 4)
+        mirt.sync()
+        st = mirt.stats()
+        assert st["kernel_ms"]["bin"] > 0 and st["kernel_ms"]["trace"] > 0 and st["gpu_ms"] >= st["kernel_ms"]["trace"]
+        with pytest.raises(mirt.MirtError):
+            mirt.previous_kernel_ms()                    # one frame in flight: the call before the last one kept nothing
+        mirt.set_frames_in_flight(2)
+        for i, v in enumerate(views):
+            mirt.raytrace_device(v, mirt.DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, outs[i & 1].ptr, W * 4)
+        prev, gpu_ms = mirt.previous_kernel_ms()
+        last = mirt.stats()
+        assert prev["bin"] > 0 and prev["trace"] > 0 and gpu_ms >= prev["trace"]
+        assert last["kernel_ms"]["trace"] > 0
+        assert prev["raster_frag"] == 0 and prev["dof"] == 0
+    finally:
+        mirt.set_frames_in_flight(1)
+        mirt.set_profiling(False)
+
+
 # ---- the C++ host adapter (reference-shaped Draw()) ---------------------------------------------------
 
 @pytest.mark.parametrize("which", ["rt", "rtsoft", "rtaa", "rtdof", "raster", "rasterdof", "rtasync", "rasterasync"])
