@@ -784,6 +784,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     const dim3 tgrid((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2);
     if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace<true>, tgrid, dim3(256), lds, g.stream, tf);
     else hipLaunchKernelGGL(k_rt_trace<false>, tgrid, dim3(256), lds, g.stream, tf);
+    k_end(MIRT_K_TRACE);                                     // (the guard below is not part of the trace kernel's time)
     {
         // the safety net of a pair list sized without a read-back (bin_pass): leaves at once unless the list overflowed
         RtFrame bf = f;
@@ -794,7 +795,6 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         hipLaunchKernelGGL(k_rt_brute_guard, dim3((unsigned)std::min<long long>((long long)nbx * nby, (long long)g.cu_count * 4)), dim3(256), 0, g.stream,
                            bf, S.d_bin_counters, S.cap_used, nbx, nby);
     }
-    k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
     return MIRT_OK;
