@@ -405,7 +405,9 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
         same = bool(torch.equal(got, full))
         print("rehearsal %s: the last gathered frame is identical to the single-GPU frame: %s" % (name, same), file=sys.stderr, flush=True)
         if not same:
-            raise SystemExit("rehearsal: gathered frame differs from the single-GPU frame")
+            bad_rows = torch.nonzero((got != full).any(dim=1)).flatten()
+            raise SystemExit("rehearsal: gathered frame differs from the single-GPU frame (%d words in %d rows, first row %d, last row %d; bands %s)"
+                             % (int((got != full).sum()), int(bad_rows.numel()), int(bad_rows[0]), int(bad_rows[-1]), [mirt.band_of(r, world, H) for r in range(world)]))
 
     # per-kernel durations of this rank IN THE SAME MODE as the timed loop (same frames in flight, same moving camera):
     # the library brackets every launch with hipEvents on the stream it runs on

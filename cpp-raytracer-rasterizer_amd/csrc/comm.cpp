@@ -218,7 +218,8 @@ bool comm_selfcheck(Comm *c, size_t bytes, hipStream_t stream)
     for (size_t i = 0; i < bytes; i++) pattern[i] = (unsigned char)((i * 2654435761u) >> 13);
     void *src = nullptr, *dst = nullptr;
     bool ok = hipMalloc(&src, bytes) == hipSuccess && hipMalloc(&dst, bytes) == hipSuccess &&
-              hipMemcpy(src, pattern.data(), bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dst, 0, bytes) == hipSuccess;
+              hipMemcpy(src, pattern.data(), bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dst, 0, bytes) == hipSuccess &&
+              hipDeviceSynchronize() == hipSuccess;      // (null-stream copy and fill: landed before `stream`, a non-blocking one, touches the buffers)
     if (!ok) c->err = "link check: device buffers";
     if (ok && c->shm) ok = shm_send(c, src, bytes, c->rank, stream) && shm_recv(c, dst, bytes, c->rank, stream);
     else if (ok) {

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -82,6 +83,27 @@ enum { EV_CALL0 = 0, EV_CALL1 = 1, EV_K0 = 2, EV_COUNT = 2 + 2 * 8 };
 
 // What a frame of the brute-force / binned ray-trace paths writes besides the caller's planes: one set per stream, so
 // that two frames in flight never share any of it.
+// Small parameter blocks for the device (frame descriptors, ray origins): the words travel in the KERNEL ARGUMENTS of a one-
+// workgroup kernel, which the launch copies before it returns -- ordered on the stream like any kernel and independent of when
+// the runtime reads a pageable or stack source (hipMemcpyAsync from such memory leaves that to its staging policy).
+struct UploadChunk { uint32_t w[768]; };
+__global__ __launch_bounds__(256) void k_upload_words(const UploadChunk c, uint32_t *__restrict__ dst, int nwords)
+{
+    for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = c.w[i];
+}
+hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+    const uint32_t *w = static_cast<const uint32_t *>(src);
+    uint32_t *d = static_cast<uint32_t *>(dst);
+    for (size_t off = 0, nw = bytes / 4; off < nw; off += 768) {
+        UploadChunk c;
+        const int n = (int)std::min<size_t>(768, nw - off);
+        memcpy(c.w, w + off, (size_t)n * 4);
+        hipLaunchKernelGGL(k_upload_words, dim3(1), dim3(256), 0, stream, c, d + off, n);
+    }
+    return hipGetLastError();
+}
+
 struct RtScratch {
     OriginRow *d_cam_tab = nullptr;              // n rows (cam_tab_n)
     OriginRow *d_light_tab = nullptr;            // light_tab_lights x n rows
@@ -509,8 +531,8 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
             break;
         }
         uint32_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, counter, 4, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
+        HIP_TRY(hipMemcpy(&total, counter, 4, hipMemcpyDeviceToHost));
         *npairs = total;
         S.known_pairs = total; S.have_known = true;
         S.count_pending = false;                             // (a count still on its way belongs to an earlier pass, maybe of another kind)
@@ -604,14 +626,14 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
     }
     if (!C.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_frames), sizeof(BinFrameDesc) * 6 * MIRT_MAX_LIGHTS));
     if (!C.d_origins) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
-    if (!C.d_counter) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_counter), 64)); HIP_TRY(hipMemset(C.d_counter, 0, 64)); }
+    if (!C.d_counter) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_counter), 64)); HIP_TRY(hipMemsetAsync(C.d_counter, 0, 64, g.stream)); }   // (ON the stream: see zero-fill note at S.d_bin_counters)
     C.nbins = nbins;
     C.nrows = 0;
     if (nlights > 0) {
         BinFrameDesc frames[6 * MIRT_MAX_LIGHTS];
         fill_light_frames(frames, f, nlights, cube_bins, 0u);
-        HIP_TRY(hipMemcpyAsync(C.d_frames, frames, sizeof(BinFrameDesc) * 6 * nlights, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(C.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(upload_small(C.d_frames, frames, sizeof(BinFrameDesc) * 6 * nlights, g.stream));
+        HIP_TRY(upload_small(C.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
         hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, nlights), dim3(256), 0, g.stream,
                            g.d_tris, g.n, C.d_origins, V3(0.0f, 0.0f, 0.0f), 1, (OriginRow *)nullptr, C.d_light_tab, (uint32_t *)nullptr,
                            (unsigned long long *)nullptr, C.d_counter);
@@ -707,7 +729,11 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         S.cap_bins = (uint32_t)cap;
         S.bin_key_valid = false;
     }
-    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 64)); HIP_TRY(hipMemset(S.d_bin_counters, 0, 64)); }
+    // Zero-fill ON the stream that uses the buffer: hipMemset runs on the null stream, which the library's non-blocking streams
+    // are not ordered with -- with several processes on one device (three ranks rehearsing a sharded run) such a fill has been seen
+    // to land AFTER the first kernels of g.stream had started counting, which cut the pair count short (a light cube built from
+    // it kept wrong shadows until the lights moved; a camera pass failed with "produced N pairs twice").
+    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 64)); HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 64, g.stream)); }
     bs.bin_off = S.d_bin_off;
 
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
@@ -728,11 +754,11 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
             S.light_tab_n = g.n;
         }
         if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * (1 + 6 * MIRT_MAX_LIGHTS)));
-        static thread_local BinFrameDesc frames[1 + 6 * MIRT_MAX_LIGHTS];
+        BinFrameDesc frames[1 + 6 * MIRT_MAX_LIGHTS];
         frames[0] = bs.frame0;
         fill_light_frames(frames + 1, f, nlights, cube_bins, cam_keys);
-        HIP_TRY(hipMemcpyAsync(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(upload_small(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), g.stream));
+        HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
         bs.frames = S.d_frames; bs.nframes = 1 + 6 * nlights;
         // first kernel of the frame: origin rows of the camera and of every light; it also zeroes the hit and pair counters
         hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1 + nlights), dim3(256), 0, g.stream,
@@ -920,7 +946,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             S.light_tab_n = g.n;
         }
         if (!S.d_origins) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
-        if (!S.d_flags) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_flags), 16)); HIP_TRY(hipMemset(S.d_flags, 0, 16)); }
+        if (!S.d_flags) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_flags), 16)); HIP_TRY(hipMemsetAsync(S.d_flags, 0, 16, g.stream)); }
     }
     f.cam_tab = S.d_cam_tab;
     f.light_tab = S.d_light_tab;
@@ -993,9 +1019,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
 
     if (binned) return rt_enqueue_binned(f, view, S, origins, nlights, y0, y1);
 
-    HIP_TRY(hipMemcpyAsync(S.d_flags, flags_init, sizeof flags_init, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(upload_small(S.d_flags, flags_init, sizeof flags_init, g.stream));
     g.hits_clean[g.hits_cur] = false;
-    HIP_TRY(hipMemcpyAsync(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
 
     k_begin(MIRT_K_PREP);
     hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1 + nlights), dim3(256), 0, g.stream,
@@ -1154,12 +1180,13 @@ extern "C" int mirt_init(int device)
     g.ev_cur = 0; g.ev = g.ev_sets[0]; g.ev_used = g.ev_used_sets[0];
     for (int i = 0; i < 4; i++) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits2[i]), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
-        HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
+        HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));   // (mirt_init ends with a device sync)
         g.hits_clean[i] = true;
     }
     for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_tile_tab[i]), sizeof(float4) * 64 * (12 + 3 * MIRT_MAX_LIGHTS)));
     g.d_hits = g.d_hits2[0];
     g.device = device;
+    HIP_TRY(hipDeviceSynchronize());             // the null-stream fills above have landed before any stream of ours runs
     g.init = true;
     return MIRT_OK;
 }
@@ -1237,6 +1264,7 @@ extern "C" int mirt_set_frames_in_flight(int frames)
     if (g.d_culled && g.n > 0) {                 // both halves of the cull flags start from the most recent ones
         const size_t from = (size_t)g.culled_latest * g.n, to = (size_t)(g.culled_latest ^ 1) * g.n;
         HIP_TRY(hipMemcpy(g.d_culled + to, g.d_culled + from, (size_t)g.n, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipDeviceSynchronize());         // (null-stream copy: landed before a frame on one of our streams reads the flags)
     }
     g.in_flight = frames;
     g.stream = g.streams[0];
@@ -1298,6 +1326,9 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
         else HIP_TRY(hipMemset(g.d_culled + (size_t)h * n, 0, (size_t)n));
     }
     if ((rc = dev_realloc(&g.d_geo, (size_t)n))) return rc;
+    // the copies and fills above ran on the null stream, which the library's non-blocking streams are not ordered with (and a
+    // copy from pageable memory may return once the source has been staged): everything has landed before a kernel reads it
+    HIP_TRY(hipDeviceSynchronize());
     hipLaunchKernelGGL(k_geo_table, dim3((n + 255) / 256), dim3(256), 0, g.stream, g.d_tris, n, g.d_geo);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g.stream));

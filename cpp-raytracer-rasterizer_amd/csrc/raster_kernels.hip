@@ -554,8 +554,8 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
         const uint64_t key = frame_key(f, scene_version);
         if (!s.sizing_valid || s.sizing_key != key) {
             uint32_t c[4] = { 0, 0, 0, 0 };               // [0] total rows, [1] overflow flag, [2] tallest triangle
-            if (hipMemcpyAsync(c, s.counters, sizeof c, hipMemcpyDeviceToHost, stream) != hipSuccess) return MIRT_ERR_HIP;
-            if (hipStreamSynchronize(stream) != hipSuccess) return MIRT_ERR_HIP;
+            if (hipStreamSynchronize(stream) != hipSuccess) return MIRT_ERR_HIP;      // (the stream first, then a synchronous copy: mirt_capi.hip bin_pass)
+            if (hipMemcpy(c, s.counters, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return MIRT_ERR_HIP;
             if (ensure_rows(s, c[0])) return MIRT_ERR_OUT_OF_MEMORY;
             s.max_rows = c[2];
             s.sizing_key = key;
