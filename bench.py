@@ -389,6 +389,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
         # words; the border is never written by the ray tracer)
         vlast = (steps * fps_step - 1) % nviews
         full = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()                         # (torch fills on ITS stream; the library's streams are not ordered with it)
         if cullers is not None:
             cullers[vlast]()
         if kind == "rt":
@@ -477,6 +478,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     covered = None
     if kind == "raster" and rank == 0 and world == 1:
         z = torch.zeros((H, W), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()                             # (torch fills on ITS stream; the library's streams are not ordered with it)
         mirt.cull_device(views[0], 3)
         mirt.rasterise_device(views[0], LIGHT, INDIRECT, 0, H, 0, bands.slot(0, 0).data_ptr(), W * 4, None, z.data_ptr(), None)
         mirt.sync()
