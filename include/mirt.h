@@ -162,7 +162,10 @@ MIRT_API int mirt_scene_soup(uint32_t seed, int n, float s, float *tris15);
 MIRT_API int mirt_cull(const float *tris15, int n, const mirt_view *view, int flags, uint8_t *culled);
 /* The same step on the device for the uploaded scene (one thread per triangle; the flags go straight into the scene's
  * device-side cull array, no host copy either way) -- what replaces the loop at rasteriser.cpp:404-447 once meshes are
- * large.  mirt_scene_get_culled reads the flags back (the reference's triangles[i].isCulled). */
+ * large.  mirt_scene_get_culled reads the flags back (the reference's triangles[i].isCulled).  The flags are those of the
+ * NEXT mirt_rasterise* call, as Update() culls right before Draw(): with mirt_set_frames_in_flight(2) they are written for,
+ * and on, the stream that call takes, so the frame still running on the other stream keeps its own -- a frame drawn as
+ * several calls (row bands) therefore culls before each of them. */
 MIRT_API int mirt_cull_device(const mirt_view *view, int flags);
 MIRT_API int mirt_scene_get_culled(uint8_t *culled, int n);
 /* LoadSTL::LoadSTLFile (rasteriser/Source/LoadSTL.cpp:17-97): reads an ASCII STL the way the reference does (every line

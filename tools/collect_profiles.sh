@@ -23,6 +23,7 @@ if [ "$stage" = pmc ]; then
   python tools/fuzz_binned.py 0 300 6 > gpurun_out/fuzz_binned_vs_brute.txt 2>&1; echo "fuzz rc=$?"
   python tools/fuzz_small.py 0 3000 > gpurun_out/fuzz_small_scenes_vs_oracle.txt 2>&1; echo "fuzz small rc=$?"
   python tools/fuzz_sequence.py 0 80 > gpurun_out/fuzz_call_sequences.txt 2>&1; echo "fuzz sequences rc=$?"
+  python tools/fuzz_raster_sequence.py 0 40 > gpurun_out/fuzz_raster_call_sequences.txt 2>&1; echo "fuzz raster sequences rc=$?"
 else
   python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench default rc=$?"
   for w in cornell1080 soup100k raster4k cornell500 cornell1080soft16 cornell1080aa3 cornell1080dof8 raster4kdof8; do

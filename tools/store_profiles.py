@@ -27,7 +27,7 @@ if traffic["workloads"]:
     json.dump(traffic, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
 if issue["workloads"]:
     json.dump(issue, open("profiles/%s_pmc_issue.json" % tag, "w"), indent=1)
-for name in ("ubench", "edgebench", "moving_light", "fuzz_binned_vs_brute", "fuzz_small_scenes_vs_oracle", "fuzz_call_sequences"):
+for name in ("ubench", "edgebench", "moving_light", "fuzz_binned_vs_brute", "fuzz_small_scenes_vs_oracle", "fuzz_call_sequences", "fuzz_raster_call_sequences"):
     src = "gpurun_out/%s.txt" % name
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, "profiles/%s_%s.txt" % (tag, name))
