@@ -21,7 +21,9 @@ mirt.init(0)
 bad = 0
 IND = (0.2, 0.2, 0.2)
 for seed in range(first, first + count):
-    rng = np.random.RandomState(15485863 * seed + 11)
+    if (seed - first) % 50 == 49:
+        print("... %d sequences, %d mismatching frames so far" % (seed - first + 1, bad), flush=True)
+    rng = np.random.RandomState((15485863 * seed + 11) % (1 << 32))
     W, H = int(rng.choice([120, 200, 257])), int(rng.choice([90, 131, 160]))
     outs = [DeviceArray((H, W), np.uint32, 0x5A) for _ in range(3)]
     k = 0

@@ -17,7 +17,9 @@ mirt.init(0)
 bad = 0
 IND = (0.2, 0.2, 0.2)
 for seed in range(first, first + count):
-    rng = np.random.RandomState(104729 * seed + 7)
+    if (seed - first) % 50 == 49:
+        print("... %d sequences, %d mismatching frames so far" % (seed - first + 1, bad), flush=True)
+    rng = np.random.RandomState((104729 * seed + 7) % (1 << 32))
     W, H = int(rng.choice([160, 256, 333])), int(rng.choice([96, 144, 200]))
     outs = [DeviceArray((H, W), np.uint32, 0x5A) for _ in range(3)]
     ref = DeviceArray((H, W), np.uint32, 0x5A)

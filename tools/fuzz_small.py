@@ -21,7 +21,7 @@ o = Oracle()
 mirt.init(0)
 bad = 0
 for seed in range(first, first + count):
-    rng = np.random.RandomState(7919 * seed + 13)
+    rng = np.random.RandomState((7919 * seed + 13) % (1 << 32))
     n = int(rng.choice([3, 5, 9, 17, 30, 31, 33, 63, 64, 65, 200, 900]))
     size = float(rng.uniform(0.2, 1.6))
     tris = mirt.scene_soup(seed, n, size)
