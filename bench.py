@@ -271,7 +271,11 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     dof = 8 if name.endswith("dof8") else 0
     mirt.set_depth_of_field(dof, 1.3 if kind == "rt" else 1.9)
 
-    depth = 2
+    # One GPU: several frames in flight, each into its own band buffer (the library takes its streams in turn, so the next
+    # frames are dispatched -- and fill the device's gaps -- while the previous ones drain).  Several GPUs: one frame in
+    # flight per rank, the RCCL gather of the previous batch overlaps it instead.
+    in_flight = int(os.environ.get("MIRT_BENCH_IN_FLIGHT", "3")) if world == 1 else 1
+    depth = max(2, in_flight)
     # Several GPUs: frames that render faster than a collective starts (the 30-triangle scenes) travel `batch` at a time --
     # one RCCL gather moves the bands of 32 consecutive frames; heavy frames (the soups: milliseconds) go one per gather.
     # Every frame is still rendered, gathered and assembled inside the timed region.
@@ -279,10 +283,6 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     native = getattr(env, "native", False)
     bands = BandGather(H, W, dev, depth=depth, batch=1 if native else batch, via_host=env.rehearsal)
     y0, y1 = bands.y0, bands.y1
-    # One GPU: two frames in flight, alternating between the two bands (the library alternates between two streams, so the
-    # next frame is dispatched while the previous one drains).  Several GPUs: one frame in flight per rank, the RCCL gather
-    # of the previous batch overlaps it instead.
-    in_flight = 2 if world == 1 else 1
     mirt.set_frames_in_flight(in_flight)
     cull_per_frame = kind == "raster" and moving        # the rasteriser's Update() culls for the new view (rasteriser.cpp:404-447)
     renders = {}                                          # (view, buffer, slot) -> callable that enqueues the frame
@@ -335,7 +335,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
         if cullers is not None:
             cullers[v]()
         if world == 1:
-            render_fn(v, i & 1, 0)()
+            render_fn(v, i % depth, 0)()
             return
         # Double-buffered band buffers: batch j renders into buffer j%2 on mirt's stream while the RCCL gather of batch
         # j-1 (the other buffer) is still in flight on the communication stream.  Dependencies are two events per buffer.
@@ -417,7 +417,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     # does; the last frame of a run drains alone and would read like a single-stream launch.
     mirt.set_profiling(True)
     kacc, kn = {}, 0
-    overlapped = in_flight == 2 and not native and batch == 1
+    overlapped = in_flight >= 2 and not native and batch == 1
     for i in range(max(4, min(steps * fps_step, 64) // 4)):
         for _ in range(6 if overlapped else 1):
             frame()

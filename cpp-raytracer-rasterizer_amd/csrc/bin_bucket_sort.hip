@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_bs_scatter(const uint32_t *__restrict__
     // the pair count for the host (pinned, mapped memory; nullable): how the next frames size their lists -- stored from here
     // rather than by a copy command, which would sit in the stream between the binning and the sort
     if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = *total_ptr;
-    if (*total_ptr > cap) return;                        // the list overflowed: this frame falls back (k_rt_brute_guard), nothing to sort
+    if (*total_ptr > cap) return;                        // the list overflowed: this frame falls back to brute force (k_rt_trace2), nothing to sort
     uint32_t *s_base = s_dyn, *s_cnt = s_dyn + nbuckets;
     // bucket_base[b] = pairs in buckets < b: every workgroup scans the counts for itself; workgroup 0 publishes the result
     uint32_t carry = 0;

@@ -37,25 +37,32 @@ __global__ void k_tile_tables(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile2(const RtTileFrame);
 __global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
-__global__ void k_bin_offsets(const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *);
-struct RtTraceFrame {
+struct TilePairRec { uint32_t tile, beg, nA, nB; };
+constexpr int ORDER_CLASSES = 8;
+struct RtTraceFrame {                            // (rt_trace.hip)
     RtFrame f;
     const uint32_t *cam_off;
     const uint32_t *cam_entries;
     const GeoRow *geo;
+    const ShadeRow *shade;
     const uint32_t *light_off;
     const LightRow *light_rows;
+    const BinFrameDesc *light_frames;
     int tiles_x;
     int cube_bins;
     int cam_shells;
+    int light_shells;
     const uint32_t *pair_count;
     uint32_t pair_cap;
+    const TilePairRec *order;
+    const uint32_t *order_count;
+    uint32_t npairs;
 };
-template <bool AA> __global__ void k_rt_trace(const RtTraceFrame);
-__global__ void k_rt_brute_guard(const RtFrame, const uint32_t *, uint32_t, int, int);
-__global__ void k_geo_table(const float *, int, GeoRow *);
+template <bool AA> __global__ void k_rt_trace2(const RtTraceFrame);
+__global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *);
+__global__ void k_geo_table(const float *, int, GeoRow *, ShadeRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t);
-size_t rt_trace_lds_bytes();
+size_t rt_trace_lds_bytes(int waves);
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
 __global__ void k_cull(const float *, int, const CullParams, uint8_t *);
 
@@ -80,6 +87,7 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 enum { EV_CALL0 = 0, EV_CALL1 = 1, EV_K0 = 2, EV_COUNT = 2 + 2 * 8 };
+constexpr int MAX_FLIGHT = 4;                    // most frames in flight (mirt_set_frames_in_flight): one HIP stream and one set of scratch each
 
 // What a frame of the brute-force / binned ray-trace paths writes besides the caller's planes: one set per stream, so
 // that two frames in flight never share any of it.
@@ -115,15 +123,13 @@ struct RtScratch {
     uint32_t *d_bin_off = nullptr, *d_bin_counters = nullptr;
     uint32_t *d_entries = nullptr;               // triangle ids ordered by bin (the sorted pair values)
     uint32_t *d_pair_keys = nullptr, *d_pair_vals = nullptr, *d_sorted_keys = nullptr;   // unsorted pairs, sorted bin ids
-    void *d_sort_temp = nullptr;
-    size_t sort_temp_bytes = 0;
     uint32_t *d_tmp_vals = nullptr;              // bucket sort: the pairs partitioned by bucket (keys go to d_sorted_keys)
     uint32_t *d_bucket = nullptr;                // bucket sort: counts | bases (+1) | cursors, cap_buckets each
     uint32_t cap_buckets = 0;
     bool bucket_dirty = false;                   // d_bucket may hold counts of a pass whose sort never ran
     // sizing the pair list without a host sync: the count of a frame is copied to pinned memory behind it and looked at by a
     // LATER frame of this stream; meanwhile the list is sized from the last count seen, with a device-side fallback if that
-    // was too small (k_rt_brute_guard)
+    // was too small (k_rt_trace2 then takes every triangle for every tile)
     uint32_t *h_count = nullptr;                 // pinned
     hipEvent_t ev_count = nullptr;
     bool count_pending = false;
@@ -137,6 +143,9 @@ struct RtScratch {
     // lights that moved: this stream's own light-cube pass (rt_enqueue_binned), rows in the order of the pair list
     LightRow *d_light_rows = nullptr;
     uint32_t cap_light_rows = 0;
+    // the frame's tile pairs ordered longest lists first (k_tile_order): ORDER_CLASSES segments of cap_order records
+    TilePairRec *d_order = nullptr;
+    uint32_t cap_order = 0;
     int last_bin_mode = -1;                      // what the last pass binned (camera alone / camera + n light cubes): a guessed
                                                  // list size only carries over between passes of the same kind
 };
@@ -154,8 +163,9 @@ struct LightCache {
     BinFrameDesc *d_frames = nullptr;            // 6 x nl frame descriptors
     uint32_t *d_off = nullptr;                   // nbins + 1
     uint32_t cap_bins = 0, nbins = 0;
-    LightRow *d_rows = nullptr;                  // expanded candidates in bin order
+    LightRow *d_rows = nullptr;                  // expanded candidates in key order
     uint32_t cap_rows = 0, nrows = 0;
+    int shells = 1;                              // depth shells per bin of the tables held
     float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
     uint32_t *d_counter = nullptr;               // pair counter of the build
 };
@@ -166,18 +176,16 @@ struct Ctx {
     int device = -1;
     int cu_count = 256;                          // multiProcessorCount of the device
     hipStream_t stream = nullptr;                // the stream of the current call (one of streams[])
-    hipStream_t streams[2] = { nullptr, nullptr };
+    hipStream_t streams[MAX_FLIGHT] = {};
     int in_flight = 1;                           // frames that may be in flight at once (mirt_set_frames_in_flight)
     uint64_t frame_no = 0;                       // device calls so far
-    int last_stream = 1;                         // index of the stream the previous call ran on (in_flight == 2)
-    bool last_self_contained = false;            // ... and whether that call may overlap its neighbours
-    hipEvent_t ev_chain = nullptr;               // orders a call after the previous one when it must not overlap it
-    hipEvent_t ev_cull = nullptr;                // orders the frames of the other stream after mirt_cull_device
-    // profiling events: one set per stream, so that the times of a frame survive the frame that follows it on the other stream
+    int si = 0;                                  // index of the stream of the current / most recent call: calls take the streams in turn
+    hipEvent_t ev_order[MAX_FLIGHT] = {};        // one per stream: orders work of one stream after what another has queued so far
+    // profiling events: one set per stream, so that the times of a frame survive the frames that follow it on the other streams
     // (mirt_get_previous_kernel_ms: the frame before the last one overlapped its neighbours on both sides)
-    hipEvent_t ev_sets[2][EV_COUNT] = {};
-    bool ev_used_sets[2][8] = {};
-    bool call_timed_sets[2] = { false, false };
+    hipEvent_t ev_sets[MAX_FLIGHT][EV_COUNT] = {};
+    bool ev_used_sets[MAX_FLIGHT][8] = {};
+    bool call_timed_sets[MAX_FLIGHT] = {};
     int ev_cur = 0;                              // the set of the current / most recent call
     hipEvent_t *ev = ev_sets[0];
     bool *ev_used = ev_used_sets[0];
@@ -185,18 +193,21 @@ struct Ctx {
     // scene
     int n = 0;
     float *d_tris = nullptr;
-    uint8_t *d_culled = nullptr;                 // isCulled flags: [0, n) for frames on streams[0], [n, 2n) for streams[1] (frames in flight)
-    int culled_latest = 0;                       // which half the most recent cull call wrote (mirt_scene_get_culled reads it)
-    RtScratch rt[2];                             // per-stream tables of the non-tile ray-trace paths (frames in flight)
+    uint8_t *d_culled = nullptr;                 // isCulled flags: one copy of n per stream, [i * n, (i + 1) * n) for frames on streams[i]
+    int culled_latest = 0;                       // which copy the most recent cull call wrote (mirt_scene_get_culled reads it)
+    uint64_t culled_ver[MAX_FLIGHT] = {};        // what each copy holds: the number of the cull call (or upload) it comes from
+    uint64_t cull_calls = 0;
+    RtScratch rt[MAX_FLIGHT];                    // per-stream tables of the non-tile ray-trace paths (frames in flight)
     GeoRow *d_geo = nullptr;                     // n geometry rows (built by mirt_scene_upload)
+    ShadeRow *d_shade = nullptr;                 // n shading rows (likewise)
     float bbox_lo[3] = { 0, 0, 0 }, bbox_hi[3] = { 0, 0, 0 };   // the scene's bounding box (host side, mirt_scene_upload)
     LightCache lc;
     unsigned long long *d_hits = nullptr;        // the hit-counter buffer of the current frame (one of d_hits2)
-    unsigned long long *d_hits2[4] = { nullptr, nullptr, nullptr, nullptr };   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits)
-    bool hits_clean[4] = { false, false, false, false };   // buffer is all zero (the tile kernel clears the one two frames ahead itself)
+    unsigned long long *d_hits2[2 * MAX_FLIGHT] = {};   // HIT_SHARDS sharded counters each (rt_common.hpp: count_hits): two per stream, [si + MAX_FLIGHT * toggle]
+    bool hits_clean[2 * MAX_FLIGHT] = {};        // buffer is all zero (the tile kernel clears its stream's other one itself)
     int hits_cur = 0;
-    float4 *d_tile_tab[2] = { nullptr, nullptr };   // per-stream tables of the tile ray tracer (k_tile_tables)
-    int hits_tog[2] = { 0, 0 };
+    float4 *d_tile_tab[MAX_FLIGHT] = {};         // per-stream tables of the tile ray tracer (k_tile_tables)
+    int hits_tog[MAX_FLIGHT] = {};
     bool scene_finite = true;                    // all vertex coordinates below MIRT_SAFE_MAG
     uint64_t scene_version = 0;                  // bumped whenever the triangles change
     uint64_t cull_version = 0;                   // bumped whenever the cull flags change (rasteriser sizing only)
@@ -210,7 +221,7 @@ struct Ctx {
         int32_t *index = nullptr;
         float *zinv = nullptr;
         size_t cap_px = 0;
-    } dof[2];
+    } dof[MAX_FLIGHT];
     int soft_npos = 0;
     float soft_pos[MIRT_MAX_LIGHTS * 3] = {};    // jittered light positions, [light*samples + i]
 
@@ -220,12 +231,11 @@ struct Ctx {
     // staging for the host-buffer entry points
     void *d_xrgb = nullptr, *d_rgb = nullptr, *d_index = nullptr, *d_zinv = nullptr, *d_pos = nullptr;
     size_t cap_px = 0;
-    // ... and for the asynchronous ones: two XRGB planes used in turn (frame i + 2 runs on the stream of frame i, or behind a
-    // barrier call, so it is ordered after the copy that reads frame i's plane)
-    void *d_async[2] = { nullptr, nullptr };
+    // ... and for the asynchronous ones: one XRGB plane per stream -- the frame that reuses a plane is queued on the stream
+    // whose copy engine read it last, so the render is ordered after that copy whatever other calls came in between
+    void *d_async[MAX_FLIGHT] = {};
     size_t async_cap_px = 0;
-    unsigned async_no = 0;
-    RasterScratch raster[2];                     // one set of rasteriser scratch per stream (frames in flight)
+    RasterScratch raster[MAX_FLIGHT];            // one set of rasteriser scratch per stream (frames in flight)
 
     // several GPUs: this process's place among the ranks that shard a frame, and its band buffers (two: the gather of one
     // batch overlaps the render of the next)
@@ -308,11 +318,11 @@ int check_view(const mirt_view *v, const mirt_light *lights, int nlights, const 
 }
 
 void k_begin(int k) { if (g.profiling) { (void)hipEventRecord(g.ev[EV_K0 + 2 * k], g.stream); g.ev_used[k] = true; } }
-// Waits for every call enqueued so far (both streams).
+// Waits for every call enqueued so far (all streams).
 hipError_t sync_all()
 {
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MAX_FLIGHT; i++)
         if (g.streams[i]) { const hipError_t r = hipStreamSynchronize(g.streams[i]); if (r != hipSuccess) e = r; }
     if (g.comm_stream) { const hipError_t r = hipStreamSynchronize(g.comm_stream); if (r != hipSuccess) e = r; }
     return e;
@@ -320,37 +330,24 @@ hipError_t sync_all()
 
 void k_end(int k) { if (g.profiling) (void)hipEventRecord(g.ev[EV_K0 + 2 * k + 1], g.stream); }
 
-// Every device call starts here.  With two frames in flight, calls that are `self_contained` (the tile ray tracer:
-// everything in LDS, hit counters per stream) alternate between two streams, so frame i+1 is dispatched while frame i
-// still drains -- no dispatch gap, no idle tail; frames i and i+2, which a double-buffering caller gives the same
-// planes, stay on one stream.  A call that touches library state shared between frames (origin tables, bins, raster
-// scratch, the depth-of-field planes) is a full barrier: it runs after every earlier call and every later call runs
-// after it.  Runs of such calls stay on one stream (stream order is cheaper than cross-stream events).
-void call_begin(bool self_contained = false)
+// The stream the NEXT device call will take: calls take the in_flight streams in turn.
+int next_si() { return g.in_flight > 1 ? (g.si + 1) % g.in_flight : 0; }
+
+// Every device call starts here.  With several frames in flight consecutive calls take the streams in turn, so frame i+1 is
+// dispatched -- and its kernels run, where the device has room -- while frame i still drains: no dispatch gap, no idle tail,
+// and the latency-bound chains of consecutive frames (binning, sort, trace; vertex, edges, fragments, resolve) fill each
+// other's gaps.  A frame reads the scene and writes the caller's planes plus its OWN stream's scratch (origin tables, bins,
+// raster keys, depth-of-field planes, counters), so frames need no ordering among themselves; frames i and i + in_flight,
+// which a caller cycling through in_flight sets of planes gives the same planes, share a stream.
+void call_begin()
 {
-    if (g.in_flight == 2) {
-        const int last = g.last_stream;
-        if (self_contained) {
-            g.stream = g.streams[last ^ 1];
-            if (!g.last_self_contained) {                        // first frame after a barrier call: order it after that call
-                (void)hipEventRecord(g.ev_chain, g.streams[last]);
-                (void)hipStreamWaitEvent(g.stream, g.ev_chain, 0);
-            }
-            g.last_stream = last ^ 1;
-        } else {
-            g.stream = g.streams[last];
-            if (g.last_self_contained) {                         // the frame before the last one may still run on the other stream
-                (void)hipEventRecord(g.ev_chain, g.streams[last ^ 1]);
-                (void)hipStreamWaitEvent(g.stream, g.ev_chain, 0);
-            }
-        }
-        g.last_self_contained = self_contained;
-    }
+    g.si = next_si();
+    g.stream = g.streams[g.si];
     g.frame_no++;
     (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (torch polls events:
                                                  // hipErrorNotReady) so that the launch checks below report our own launches only
     memset(&g.stats, 0, sizeof g.stats);
-    g.ev_cur = (g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0;
+    g.ev_cur = g.si;
     g.ev = g.ev_sets[g.ev_cur];
     g.ev_used = g.ev_used_sets[g.ev_cur];
     memset(g.ev_used, 0, sizeof g.ev_used_sets[0]);
@@ -423,29 +420,20 @@ int ensure_pairs(RtScratch &S, size_t cap)
     int r;
     if ((r = dev_realloc(&S.d_entries, cap)) || (r = dev_realloc(&S.d_pair_keys, cap)) || (r = dev_realloc(&S.d_pair_vals, cap)) ||
         (r = dev_realloc(&S.d_sorted_keys, cap)) || (r = dev_realloc(&S.d_tmp_vals, cap))) { S.cap_entries = 0; return r; }
-    const size_t need = bin_sort_temp_bytes((uint32_t)cap, 32);
-    if (need == 0) return fail(MIRT_ERR_HIP, "radix sort: cannot size its temporary storage for %zu pairs", cap);
-    if (need > S.sort_temp_bytes) {
-        if (S.d_sort_temp) (void)hipFree(S.d_sort_temp);
-        S.d_sort_temp = nullptr; S.sort_temp_bytes = 0;
-        if (hipMalloc(&S.d_sort_temp, need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "radix sort scratch (%zu bytes)", need);
-        S.sort_temp_bytes = need;
-    }
     S.cap_entries = (uint32_t)cap;
     return MIRT_OK;
 }
 
-int key_bits_for(uint32_t nbins)
-{
-    int bits = 1;
-    while ((1u << bits) < nbins && bits < 32) bits++;
-    return bits;
-}
+// Most sort keys (bin * depth shells + shell) one binning pass may use: the two-level counting sort keeps one LDS counter per
+// bucket of at most 1024 keys (bin_bucket_sort.hip).  The callers choose their grids and shell counts to stay below it.
+constexpr uint32_t BIN_MAX_KEYS = BUCKET_SORT_MAX_BUCKETS * 1024u - 1u;
 
-// One binning pass on g.stream: (bin, triangle) pairs of `bs`' frames into S' pair list, ordered by bin into S.d_entries /
+// One binning pass on g.stream: (key, triangle) pairs of `bs`' frames into S' pair list, ordered by key into S.d_entries /
 // S.d_sorted_keys, offsets into bin_off.  `counter` (device, zeroed by the caller's previous kernel) receives the pair
 // count.  The list is sized from a count only the device knows: when `fresh` it is read back (4 bytes + one sync of this
 // stream) and the pass repeated if the list was too small; otherwise *npairs, the count of the identical pass before, holds.
+// A pass that may not read back (`may_guess`) sizes the list from the count an earlier pass published and publishes its own;
+// a list that turns out too small makes the frame's kernels take the brute-force path (k_rt_trace2) and the NEXT pass grow it.
 int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow *light_tab, uint32_t *counter, uint32_t *bin_off,
              bool fresh, uint32_t *npairs, bool may_guess = false)
 {
@@ -456,38 +444,35 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     }
     (void)hipGetLastError();                                 // (hipErrorNotReady of the query is not an error)
     static const bool always_sync = [] { const char *e = getenv("MIRT_BIN_SYNC"); return e && atoi(e) != 0; }();
+    // A pass identical to the one before it (same view, same scene) normally reuses that pass's count without looking; but if
+    // that pass was itself a guess and its published count shows the list was too small, the frame fell back to brute force
+    // and so would every later frame of this view: treat it as fresh again so that the list grows.
+    if (!fresh && may_guess && S.have_known && S.known_pairs > S.cap_used) fresh = true;
     const bool guess = fresh && may_guess && S.have_known && !always_sync;
     if (!S.d_entries || !S.cap_entries) {
         // first capacity of the pair list (grown on demand below); MIRT_BIN_INITIAL_PAIRS lets a test start small
         static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
         if ((rc = ensure_pairs(S, initial))) return rc;
     }
+    if (bs.nbins > BIN_MAX_KEYS) return fail(MIRT_ERR_INVALID_ARGUMENT, "binning: %u sort keys exceed the %u the bucket sort holds", bs.nbins, BIN_MAX_KEYS);
     // workgroups striding over the (256-triangle chunk, frame) work items: 8 per CU (52 KiB of LDS and 512 threads each, 3 resident; 1 M
-    // triangles at 8K: 4.06 -> 3.53 ms per frame against 3 per CU); MIRT_BIN_WGS overrides
-    static const int bin_wgs = [] { const char *e = getenv("MIRT_BIN_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 16) ? v : 8; }();
-    static const int chunk_env = [] { const char *e = getenv("MIRT_BIN_CHUNK"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
-    bs.chunk_tris = chunk_env ? chunk_env : 256;        // (64 measured slower on the 100 k soup: 86 vs 74 us for the whole binning, more flushes)
-    const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + bs.chunk_tris - 1) / bs.chunk_tris) * bs.nframes, (long long)g.cu_count * bin_wgs));
+    // triangles at 8K: 4.06 -> 3.53 ms per frame against 3 per CU)
+    bs.chunk_tris = 256;                                // (64 measured slower on the 100 k soup: 86 vs 74 us for the whole binning, more flushes)
+    const dim3 bin_grid((unsigned)std::min<long long>((long long)((g.n + bs.chunk_tris - 1) / bs.chunk_tris) * bs.nframes, (long long)g.cu_count * 8));
     bs.counters = counter;
-    // order the pairs by bin with the two-level counting sort on the bin id (bin_bucket_sort.hip: k_bin_pairs counts the pairs
-    // per bucket, two more launches sort), or -- when the bins are too many for its LDS histograms, or MIRT_BIN_SORT=rocprim --
-    // with rocPRIM's radix sort + a binary search per bin
-    static const bool force_generic = [] { const char *e = getenv("MIRT_BIN_SORT"); return e && !strcmp(e, "rocprim"); }();
+    // order the pairs by key with the two-level counting sort (bin_bucket_sort.hip: k_bin_pairs counts the pairs per bucket,
+    // two more launches sort)
     const uint32_t nbuckets = bucket_sort_buckets(bs.nbins);
-    const bool bucket_sort = !force_generic && nbuckets <= BUCKET_SORT_MAX_BUCKETS;
-    uint32_t *bcnt = nullptr, *bbase = nullptr, *bcur = nullptr;
-    if (bucket_sort) {
-        if (nbuckets + 1 > S.cap_buckets) {
-            S.cap_buckets = 0;
-            if ((rc = dev_realloc(&S.d_bucket, (size_t)3 * (nbuckets + 1)))) return rc;
-            HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (nbuckets + 1), g.stream));
-            S.cap_buckets = nbuckets + 1;
-            S.bucket_dirty = false;
-        }
-        bcnt = S.d_bucket; bbase = S.d_bucket + S.cap_buckets; bcur = S.d_bucket + 2 * (size_t)S.cap_buckets;
-        bs.bucket_cnt = bcnt; bs.nbuckets = nbuckets; bs.bucket_shift = bucket_sort_shift(bs.nbins);
+    if (nbuckets + 1 > S.cap_buckets) {
+        S.cap_buckets = 0;
+        if ((rc = dev_realloc(&S.d_bucket, (size_t)3 * (nbuckets + 1)))) return rc;
+        HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (nbuckets + 1), g.stream));
+        S.cap_buckets = nbuckets + 1;
+        S.bucket_dirty = false;
     }
-    const size_t bin_lds = bucket_sort ? (size_t)nbuckets * sizeof(uint32_t) : 0;
+    uint32_t *bcnt = S.d_bucket, *bbase = S.d_bucket + S.cap_buckets, *bcur = S.d_bucket + 2 * (size_t)S.cap_buckets;
+    bs.bucket_cnt = bcnt; bs.nbuckets = nbuckets; bs.bucket_shift = bucket_sort_shift(bs.nbins);
+    const size_t bin_lds = (size_t)nbuckets * sizeof(uint32_t);
     {   // k_bin_pairs: ~52 KB of static LDS + up to 32 KB of bucket counters: past the 64 KB a launch may use by default
         static const bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); return true; }();
         (void)once;
@@ -508,25 +493,17 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         BinPairs pairs = { S.d_pair_keys, S.d_pair_vals, S.cap_used };
         bs.entries = S.d_entries; bs.cap_entries = S.cap_used;
         if (attempt) HIP_TRY(hipMemsetAsync(counter, 0, 4, g.stream));
-        if (bucket_sort && (attempt || S.bucket_dirty)) HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (size_t)S.cap_buckets, g.stream));
-        S.bucket_dirty = bucket_sort;                        // bucket counts pending until k_bs_local has consumed them
+        if (attempt || S.bucket_dirty) HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (size_t)S.cap_buckets, g.stream));
+        S.bucket_dirty = true;                               // bucket counts pending until k_bs_local has consumed them
         hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(BIN_WG), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
         if (!fresh) break;
         if (guess) {
-            // no sync: the count travels to pinned memory behind the kernel and a later frame picks it up
+            // no sync: k_bs_scatter stores the count into a pinned word behind the kernel and a later frame picks it up
             if (!S.h_count) {
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.h_count), 64, hipHostMallocDefault));
                 HIP_TRY(hipEventCreateWithFlags(&S.ev_count, hipEventDisableTiming));
             }
-            if (!S.count_pending) {
-                if (bucket_sort) {
-                    publish_count = true;                    // k_bs_scatter stores the count into the pinned word (below)
-                } else {
-                    HIP_TRY(hipMemcpyAsync(S.h_count, counter, 4, hipMemcpyDeviceToHost, g.stream));
-                    HIP_TRY(hipEventRecord(S.ev_count, g.stream));
-                    S.count_pending = true;
-                }
-            }
+            if (!S.count_pending) publish_count = true;
             *npairs = S.known_pairs;
             break;
         }
@@ -550,20 +527,15 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         (void)hipMemset(counter + 2, 0, 56);
     }
 #endif
-    if (bucket_sort) {
-        uint32_t *count_out = nullptr;
-        if (publish_count) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&count_out), S.h_count, 0));
-        HIP_TRY(bucket_sort_pairs(S.d_pair_keys, S.d_pair_vals, counter, S.cap_used, *npairs, bs.nbins, S.d_sorted_keys, S.d_tmp_vals,
-                                  bcnt, bbase, bcur, bin_off, S.d_entries, g.cu_count, g.stream, count_out));
-        S.bucket_dirty = false;                              // k_bs_local leaves the counts and cursors zero
-        if (publish_count) {
-            HIP_TRY(hipEventRecord(S.ev_count, g.stream));
-            S.count_pending = true;
-        }
-        return MIRT_OK;
+    uint32_t *count_out = nullptr;
+    if (publish_count) HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&count_out), S.h_count, 0));
+    HIP_TRY(bucket_sort_pairs(S.d_pair_keys, S.d_pair_vals, counter, S.cap_used, *npairs, bs.nbins, S.d_sorted_keys, S.d_tmp_vals,
+                              bcnt, bbase, bcur, bin_off, S.d_entries, g.cu_count, g.stream, count_out));
+    S.bucket_dirty = false;                                  // k_bs_local leaves the counts and cursors zero
+    if (publish_count) {
+        HIP_TRY(hipEventRecord(S.ev_count, g.stream));
+        S.count_pending = true;
     }
-    HIP_TRY(bin_sort_pairs(S.d_sort_temp, S.sort_temp_bytes, S.d_pair_keys, S.d_sorted_keys, S.d_pair_vals, S.d_entries, *npairs, key_bits_for(bs.nbins), g.stream));
-    hipLaunchKernelGGL(k_bin_offsets, dim3((bs.nbins + 1 + 255) / 256), dim3(256), 0, g.stream, S.d_sorted_keys, counter, S.cap_used, bs.nbins, bin_off);
     return MIRT_OK;
 }
 
@@ -576,11 +548,28 @@ uint64_t light_key_of(const float *origins, int nlights)
     return key;
 }
 
-// Frame descriptors of the light cubes: six faces of B x B bins around every light position, bins numbered from `base`.
-void fill_light_frames(BinFrameDesc *frames, const RtFrame &f, int nlights, int cube_bins, uint32_t base)
+// Nearest and farthest distance from `pos` to the scene's bounding box: the range the depth shells of a ray family divide.
+bool shell_range(const float *pos, double *dn, double *df)
+{
+    double n2 = 0.0, f2 = 0.0;
+    for (int c = 0; c < 3; c++) {
+        const double p = pos[c], lo = g.bbox_lo[c], hi = g.bbox_hi[c];
+        const double near = p < lo ? lo - p : (p > hi ? p - hi : 0.0), far = std::max(std::fabs(p - lo), std::fabs(p - hi));
+        n2 += near * near; f2 += far * far;
+    }
+    *dn = std::sqrt(n2); *df = std::sqrt(f2);
+    return std::isfinite(*dn) && std::isfinite(*df) && *df > *dn;
+}
+
+// Frame descriptors of the light cubes: six faces of B x B bins around every light position, every bin's list ordered in
+// `shells` depth shells of the candidates' `near` bound (sort key = (base + bin) * shells + shell; `base_bins` = where light 0's
+// face 0 starts, in bins of `shells` keys).  A shadow ray walks only the shells up to the one its 0.99 r falls into (k_rt_trace2).
+void fill_light_frames(BinFrameDesc *frames, const RtFrame &f, int nlights, int cube_bins, int shells, uint32_t base_bins)
 {
     memset(frames, 0, sizeof(BinFrameDesc) * 6 * nlights);
-    for (int k = 0; k < nlights; k++)
+    for (int k = 0; k < nlights; k++) {
+        double dn = 0.0, df = 0.0;
+        const bool okr = shell_range(f.lpos[k], &dn, &df);
         for (int face = 0; face < 6; face++) {
             BinFrameDesc &d = frames[k * 6 + face];
             const int ax = face >> 1;
@@ -593,9 +582,26 @@ void fill_light_frames(BinFrameDesc *frames, const RtFrame &f, int nlights, int 
             d.ulo = -1.0f; d.vlo = -1.0f; d.du = 2.0f / (float)cube_bins; d.dv = 2.0f / (float)cube_bins;
             d.pad_lo = -3.814697265625e-06f; d.pad_hi = 3.814697265625e-06f;
             d.nbu = cube_bins; d.nbv = cube_bins; d.j0 = 0; d.j1 = cube_bins;
-            d.base = base; d.tab = 1 + k;
-            base += (uint32_t)(cube_bins * cube_bins);
+            d.base = base_bins; d.tab = 1 + k;
+            // every face of every light carries `shells` keys per bin (the key layout needs one count for all); a light whose
+            // range is degenerate puts everything into shell 0
+            d.nshell = shells;
+            d.shell_d0 = (float)dn;
+            d.shell_iw = okr ? (float)(shells / (df - dn)) : 0.0f;
+            base_bins += (uint32_t)(cube_bins * cube_bins);
         }
+    }
+}
+
+// Depth shells per light-cube bin: as many as the sort's key space allows, at most 16 (a bin's list grows with the square of
+// the distance from the light; 16 shells leave a ray at a quarter of the scene's depth ~2 % of it).
+int light_shells_for(int nlights, int cube_bins, uint32_t keys_in_front)
+{
+    static const int env = [] { const char *e = getenv("MIRT_LIGHT_SHELLS"); return e ? atoi(e) : 0; }();
+    const long long bins = 6ll * cube_bins * cube_bins * std::max(nlights, 1);
+    int ns = (env >= 1 && env <= 64) ? env : 16;
+    while (ns > 1 && bins * ns + keys_in_front + 64 > (long long)BIN_MAX_KEYS) ns >>= 1;
+    return ns;
 }
 
 // The SHARED light-cube bins and their expanded rows, for lights that stand still: built on g.stream as a barrier call -- the
@@ -608,30 +614,32 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
     const uint64_t key = light_key_of(origins, nlights);
     if (C.valid && C.key == key && C.cube_bins == cube_bins) return MIRT_OK;
     C.valid = false;
-    const int other = (g.stream == g.streams[0]) ? 1 : 0;
-    if (g.in_flight == 2) {                                  // frames of the other stream may still read the old tables
-        HIP_TRY(hipEventRecord(g.ev_cull, g.streams[other]));
-        HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_cull, 0));
-    }
-    const uint32_t per_light = 6u * (uint32_t)(cube_bins * cube_bins), nbins = per_light * (uint32_t)nlights;
+    for (int o = 0; o < g.in_flight; o++)                  // frames of the other streams may still read the old tables
+        if (o != g.si) {
+            HIP_TRY(hipEventRecord(g.ev_order[o], g.streams[o]));
+            HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_order[o], 0));
+        }
+    const int shells = light_shells_for(nlights, cube_bins, 0u);
+    const uint32_t per_light = 6u * (uint32_t)(cube_bins * cube_bins) * (uint32_t)shells, nkeys = per_light * (uint32_t)nlights;
     if ((size_t)nlights * g.n > C.cap_tab) {
         C.cap_tab = 0;
         if ((rc = dev_realloc(&C.d_light_tab, (size_t)nlights * g.n))) return rc;
         C.cap_tab = (size_t)nlights * g.n;
     }
-    if (nbins + 1 > C.cap_bins) {
+    if (nkeys + 1 > C.cap_bins) {
         C.cap_bins = 0;
-        if ((rc = dev_realloc(&C.d_off, (size_t)nbins + 1))) return rc;
-        C.cap_bins = nbins + 1;
+        if ((rc = dev_realloc(&C.d_off, (size_t)nkeys + 1))) return rc;
+        C.cap_bins = nkeys + 1;
     }
     if (!C.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_frames), sizeof(BinFrameDesc) * 6 * MIRT_MAX_LIGHTS));
     if (!C.d_origins) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
     if (!C.d_counter) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_counter), 64)); HIP_TRY(hipMemsetAsync(C.d_counter, 0, 64, g.stream)); }   // (ON the stream: see zero-fill note at S.d_bin_counters)
-    C.nbins = nbins;
+    C.nbins = nkeys;
     C.nrows = 0;
+    C.shells = shells;
     if (nlights > 0) {
         BinFrameDesc frames[6 * MIRT_MAX_LIGHTS];
-        fill_light_frames(frames, f, nlights, cube_bins, 0u);
+        fill_light_frames(frames, f, nlights, cube_bins, shells, 0u);
         HIP_TRY(upload_small(C.d_frames, frames, sizeof(BinFrameDesc) * 6 * nlights, g.stream));
         HIP_TRY(upload_small(C.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
         hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, nlights), dim3(256), 0, g.stream,
@@ -639,7 +647,7 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
                            (unsigned long long *)nullptr, C.d_counter);
         BinSet bs;
         memset(&bs, 0, sizeof bs);
-        bs.frames = C.d_frames; bs.nframes = 6 * nlights; bs.nbins = nbins; bs.bin_off = C.d_off;
+        bs.frames = C.d_frames; bs.nframes = 6 * nlights; bs.nbins = nkeys; bs.bin_off = C.d_off;
         uint32_t npairs = 0;
         if ((rc = bin_pass(S, bs, nullptr, C.d_light_tab, C.d_counter, C.d_off, true, &npairs))) return rc;
         if (npairs > C.cap_rows) {
@@ -657,14 +665,32 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
     } else {
         HIP_TRY(hipMemsetAsync(C.d_off, 0, 4, g.stream));
     }
-    if (g.in_flight == 2) {                                  // later frames of the other stream wait for the build
-        HIP_TRY(hipEventRecord(g.ev_cull, g.stream));
-        HIP_TRY(hipStreamWaitEvent(g.streams[other], g.ev_cull, 0));
+    if (g.in_flight > 1) {                                   // later frames of the other streams wait for the build
+        HIP_TRY(hipEventRecord(g.ev_order[g.si], g.stream));
+        for (int o = 0; o < g.in_flight; o++)
+            if (o != g.si) HIP_TRY(hipStreamWaitEvent(g.streams[o], g.ev_order[g.si], 0));
     }
     C.key = key;
     C.cube_bins = cube_bins;
     C.valid = true;
     return MIRT_OK;
+}
+
+// Depth shells of the camera bins for a frame of `tiles` bins (the tiles' lists come out of the sort roughly front to back).
+int camera_shells_for(long long tiles)
+{
+    static const int shells_env = [] { const char *e = getenv("MIRT_CAM_SHELLS"); return e ? atoi(e) : 0; }();
+    int ns = (int)std::min<long long>(8, std::max<long long>(1, (4ll << 20) / std::max<long long>(tiles, 1)));
+    if (shells_env >= 1 && shells_env <= 64) ns = shells_env;
+    while (ns > 1 && tiles * ns + 64 > (long long)BIN_MAX_KEYS) ns >>= 1;
+    return ns;
+}
+
+// Can a frame of this size be binned at all?  (one sort key per 8 x 8-pixel tile at least)
+bool frame_fits_binning(int W, int H)
+{
+    const long long tiles = (long long)((W + BIN_TILE - 1) / BIN_TILE) * ((H + BIN_TILE - 1) / BIN_TILE);
+    return tiles + 64 <= (long long)BIN_MAX_KEYS;
 }
 
 // A binned frame: camera origin rows, camera-tile bins, trace.  The light-cube bins come from the shared cache when the lights
@@ -680,12 +706,14 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     g.stats.mode_used = MIRT_RT_BINNED;
     // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists; the shared bins are built once per
     // (scene, lights), not per frame, so what they cost is memory (48 bytes per (bin, triangle) pair) and ~1 ms of build for
-    // 100 k triangles.  Measured on the 100 k soup at 1080p (trace kernel): 64: 153 us, 128: 125 us, 256: 105 us.
-    // MIRT_CUBE_BINS=64|128|256 fixes the grid (and keeps every frame on the shared cache).
+    // 100 k triangles.  Measured on the 100 k soup at 1080p (round 2's trace kernel, lists not yet ordered by depth): 64: 153 us,
+    // 128: 125 us, 256: 105 us.  MIRT_CUBE_BINS=64|128|256 fixes the grid (and keeps every frame on the shared cache).
     static const int cube_override = [] { const char *e = getenv("MIRT_CUBE_BINS"); return e ? atoi(e) : 0; }();
     int fine_bins = g.n < 2000 ? CUBE_BINS_MIN : (g.n < 20000 ? 2 * CUBE_BINS_MIN : 4 * CUBE_BINS_MIN);
     const bool fixed_grid = cube_override == 64 || cube_override == 128 || cube_override == 256;
     if (fixed_grid) fine_bins = cube_override;
+    // (many light positions -- 16 soft-shadow samples of two lights -- at the finest grid are more keys than one sort pass holds)
+    while (fine_bins > CUBE_BINS_MIN && 6ll * fine_bins * fine_bins * nlights * 4 > (long long)BIN_MAX_KEYS) fine_bins /= 2;
 
     const uint64_t lkey = light_key_of(origins, nlights);
     if (g.lc.track_key == lkey) g.lc.stable++;
@@ -704,25 +732,19 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     {
         // depth shells: the tiles' lists come out of the sort roughly front to back (key = bin * shells + shell of the
         // candidate's `near` bound, uniform steps between the nearest and the farthest point of the scene's box)
-        static const int shells_env = [] { const char *e = getenv("MIRT_CAM_SHELLS"); return e ? atoi(e) : 0; }();
-        const long long tiles = (long long)bs.frame0.nbu * bs.frame0.nbv;
-        int ns = (int)std::min<long long>(8, std::max<long long>(1, (4ll << 20) / std::max<long long>(tiles, 1)));
-        if (shells_env >= 1 && shells_env <= 64) ns = shells_env;
+        const int ns = camera_shells_for((long long)bs.frame0.nbu * bs.frame0.nbv);
         double dn = 0.0, df = 0.0;
-        for (int c = 0; c < 3; c++) {
-            const double p = view->pos[c], lo = g.bbox_lo[c], hi = g.bbox_hi[c];
-            const double near = p < lo ? lo - p : (p > hi ? p - hi : 0.0), far = std::max(std::fabs(p - lo), std::fabs(p - hi));
-            dn += near * near; df += far * far;
-        }
-        dn = std::sqrt(dn); df = std::sqrt(df);
-        const bool okr = std::isfinite(dn) && std::isfinite(df) && df > dn;
+        const bool okr = shell_range(view->pos, &dn, &df);
         bs.frame0.nshell = okr ? ns : 1;
         bs.frame0.shell_d0 = (float)dn;
         bs.frame0.shell_iw = okr ? (float)(ns / (df - dn)) : 0.0f;
     }
     const uint32_t cam_keys = (uint32_t)bs.frame0.nbu * bs.frame0.nbv * (uint32_t)bs.frame0.nshell;
-    const uint32_t per_light = 6u * (uint32_t)(cube_bins * cube_bins);
-    bs.nbins = cam_keys + (transient ? per_light * (uint32_t)nlights : 0u);
+    // this frame's own light cubes (moving lights): their keys follow the camera's, from a multiple of their shell count on
+    const int tshells = transient ? light_shells_for(nlights, cube_bins, cam_keys) : 1;
+    const uint32_t light_key0 = transient ? (cam_keys + (uint32_t)tshells - 1u) / (uint32_t)tshells * (uint32_t)tshells : cam_keys;
+    const uint32_t per_light = 6u * (uint32_t)(cube_bins * cube_bins) * (uint32_t)tshells;
+    bs.nbins = transient ? light_key0 + per_light * (uint32_t)nlights : cam_keys;
     if (bs.nbins + 1 > S.cap_bins) {
         const size_t cap = (size_t)bs.nbins + 1;
         if ((rc = dev_realloc(&S.d_bin_off, cap))) { S.cap_bins = 0; return rc; }
@@ -733,7 +755,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     // are not ordered with -- with several processes on one device (three ranks rehearsing a sharded run) such a fill has been seen
     // to land AFTER the first kernels of g.stream had started counting, which cut the pair count short (a light cube built from
     // it kept wrong shadows until the lights moved; a camera pass failed with "produced N pairs twice").
-    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 64)); HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 64, g.stream)); }
+    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 128)); HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 128, g.stream)); }
     bs.bin_off = S.d_bin_off;
 
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
@@ -744,6 +766,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     }
     const int bin_mode = transient ? 1 + nlights : 0;
     g.hits_clean[g.hits_cur] = false;
+    if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * (1 + 6 * MIRT_MAX_LIGHTS)));
     if (transient) {
         // this stream's own light tables: origin rows per light, the cubes' frame descriptors behind the camera's, the rows
         if (nlights > S.light_tab_lights || S.light_tab_n != g.n) {
@@ -753,10 +776,9 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
             S.light_tab_lights = nlights;
             S.light_tab_n = g.n;
         }
-        if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * (1 + 6 * MIRT_MAX_LIGHTS)));
         BinFrameDesc frames[1 + 6 * MIRT_MAX_LIGHTS];
         frames[0] = bs.frame0;
-        fill_light_frames(frames + 1, f, nlights, cube_bins, cam_keys);
+        fill_light_frames(frames + 1, f, nlights, cube_bins, tshells, light_key0 / (uint32_t)tshells);
         HIP_TRY(upload_small(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), g.stream));
         HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
         bs.frames = S.d_frames; bs.nframes = 1 + 6 * nlights;
@@ -787,40 +809,57 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         }
         const uint32_t expect = std::max<uint32_t>(S.bin_entries, 1u);
         hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                           S.d_bin_off + cam_keys, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used);
+                           S.d_bin_off + light_key0, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used);
+    }
+    // the order the trace kernel's waves take the tile pairs in: longest lists first
+    const uint32_t npairs = (uint32_t)((bs.frame0.nbu + 1) / 2) * (uint32_t)(bs.frame0.j1 - bs.frame0.j0);
+    if (npairs > S.cap_order) {
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        S.cap_order = 0;
+        if ((rc = dev_realloc(&S.d_order, (size_t)ORDER_CLASSES * npairs))) return rc;
+        S.cap_order = npairs;
+    }
+    hipLaunchKernelGGL(k_tile_order, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, S.d_bin_off, bs.frame0.nshell, bs.frame0.nbu,
+                       bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order);
+    if (getenv("MIRT_TR_HIST")) {
+        (void)hipStreamSynchronize(g.stream);
+        uint32_t c[32];
+        (void)hipMemcpy(c, S.d_bin_counters, 128, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mirt hist] pairs %u | tile pairs by longer list / 16:", c[0]);
+        for (int i = 16; i < 24; i++) fprintf(stderr, " %u", c[i]);
+        fprintf(stderr, "\n");
     }
     k_end(MIRT_K_BIN);
 
     RtTraceFrame tf;
     memset(&tf, 0, sizeof tf);
     tf.f = f;
+    tf.f.cam_tab = S.d_cam_tab;
+    // (a frame whose pair list overflowed walks the origin tables themselves: every triangle for every ray)
+    tf.f.light_tab = transient ? S.d_light_tab : g.lc.d_light_tab;
+    tf.f.unsafe = nullptr;
     tf.cam_off = S.d_bin_off;
     tf.cam_entries = S.d_entries;
     tf.geo = g.d_geo;
-    tf.light_off = transient ? S.d_bin_off + cam_keys : g.lc.d_off;
+    tf.shade = g.d_shade;
+    tf.light_off = transient ? S.d_bin_off + light_key0 : g.lc.d_off;
     tf.light_rows = transient ? S.d_light_rows : g.lc.d_rows;
+    tf.light_frames = transient ? S.d_frames + 1 : g.lc.d_frames;
     tf.tiles_x = bs.frame0.nbu;
     tf.cube_bins = cube_bins;
     tf.cam_shells = bs.frame0.nshell;
+    tf.light_shells = transient ? tshells : g.lc.shells;
     tf.pair_count = S.d_bin_counters;
     tf.pair_cap = S.cap_used;
-    const int tile_rows = bs.frame0.j1 - bs.frame0.j0;
-    const size_t lds = rt_trace_lds_bytes();
+    // one wave per pair of 8 x 8 tiles
+    tf.order = S.d_order; tf.order_count = S.d_bin_counters + 16; tf.npairs = npairs;
+    static const int wpb_env = [] { const char *e = getenv("MIRT_TR_WPB"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 1; }();   // (experiments: waves per workgroup)
+    const dim3 tgrid((npairs + (uint32_t)wpb_env - 1u) / (uint32_t)wpb_env);
+    const size_t lds = rt_trace_lds_bytes(wpb_env);
     k_begin(MIRT_K_TRACE);
-    const dim3 tgrid((tf.tiles_x + 1) / 2, (tile_rows + 1) / 2);
-    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace<true>, tgrid, dim3(256), lds, g.stream, tf);
-    else hipLaunchKernelGGL(k_rt_trace<false>, tgrid, dim3(256), lds, g.stream, tf);
-    k_end(MIRT_K_TRACE);                                     // (the guard below is not part of the trace kernel's time)
-    {
-        // the safety net of a pair list sized without a read-back (bin_pass): leaves at once unless the list overflowed
-        RtFrame bf = f;
-        bf.cam_tab = S.d_cam_tab;
-        bf.light_tab = transient ? S.d_light_tab : g.lc.d_light_tab;
-        bf.unsafe = nullptr;
-        const int rows = y1 - y0, nbx = (view->width + 127) / 128, nby = (rows + 3) / 4;
-        hipLaunchKernelGGL(k_rt_brute_guard, dim3((unsigned)std::min<long long>((long long)nbx * nby, (long long)g.cu_count * 4)), dim3(256), 0, g.stream,
-                           bf, S.d_bin_counters, S.cap_used, nbx, nby);
-    }
+    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace2<true>, tgrid, dim3(64 * wpb_env), lds, g.stream, tf);
+    else hipLaunchKernelGGL(k_rt_trace2<false>, tgrid, dim3(64 * wpb_env), lds, g.stream, tf);
+    k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
     return MIRT_OK;
@@ -905,6 +944,11 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
                   (mode == MIRT_RT_AUTO && g.n >= auto_threshold && (long long)view->width * (y1 - y0) > 4096 &&
                    (long long)view->width * (y1 - y0) * g.n >= 40000000LL);
     if (!safe) binned = false;
+    if (binned && !frame_fits_binning(view->width, view->height)) {
+        // more 8 x 8-pixel tiles than one sort pass has keys (a frame beyond ~23 000 x 23 000 pixels)
+        if (mode == MIRT_RT_BINNED) return fail(MIRT_ERR_INVALID_ARGUMENT, "frame %dx%d has more tiles than the binned path can key; use MIRT_RT_AUTO or row bands of a smaller frame", view->width, view->height);
+        binned = false;
+    }
     const int rows = y1 - y0;
 
     // Small scenes (the reference's own 30-triangle Cornell box): one launch, every table built in LDS by the
@@ -917,7 +961,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
 
     // A frame reads the scene and writes the caller's planes plus its stream's own tables, counters and depth-of-field
     // planes, so frames may overlap (call_begin).
-    call_begin(true);
+    call_begin();
     g.pending_is_rt = true;
     g.pending_primary = (uint64_t)view->width * (uint64_t)(y1 - y0) * (uint64_t)((g.aa > 1 ? g.aa : 1) * (g.aa > 1 ? g.aa : 1));
     g.pending_nlights = light_positions;
@@ -927,9 +971,9 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     if (y1 == y0) { call_end(); return MIRT_OK; }
     // hit counters: every stream owns two buffers used alternately, so that a kernel can clear the one the NEXT frame
     // on its stream will use
-    const int si = (g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0;
+    const int si = g.si;
     g.hits_tog[si] ^= 1;
-    g.hits_cur = si + 2 * g.hits_tog[si];
+    g.hits_cur = si + MAX_FLIGHT * g.hits_tog[si];
     g.d_hits = g.d_hits2[g.hits_cur];
     f.hit_count = g.d_hits;
     RtScratch &S = g.rt[si];
@@ -977,12 +1021,13 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
             HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
         g.hits_clean[g.hits_cur] = false;
         g.pending_counted = true;
-        tf.clear_hits = g.d_hits2[g.hits_cur ^ 2];       // zeroed by this launch for the next frame on this stream: no memset node per frame
-        g.hits_clean[g.hits_cur ^ 2] = true;
+        const int hits_other = si + MAX_FLIGHT * (g.hits_tog[si] ^ 1);
+        tf.clear_hits = g.d_hits2[hits_other];           // zeroed by this launch for the next frame on this stream: no memset node per frame
+        g.hits_clean[hits_other] = true;
         // Tables: built once per frame by k_tile_tables when the frame has enough workgroups to make rebuilding them in
         // each one the larger cost; small frames are bound by the launch rate and keep the single launch.
         static const int tab_blocks = [] { const char *e = getenv("MIRT_TILE_TABLE_BLOCKS"); return e ? atoi(e) : 1024; }();
-        tf.tables = (int)blocks >= tab_blocks ? g.d_tile_tab[g.hits_cur & 1] : nullptr;   // one table buffer per stream
+        tf.tables = (int)blocks >= tab_blocks ? g.d_tile_tab[si] : nullptr;   // one table buffer per stream
         if (tf.tables) {
             k_begin(MIRT_K_PREP);
             hipLaunchKernelGGL(k_tile_tables, dim3(1), dim3(64), 0, g.stream, tf);
@@ -1104,7 +1149,7 @@ int render_with_dof(const mirt_view *view, int y0, int y1, int row_origin, void 
     const int ry0 = std::max(0, y0 - reach), ry1 = std::min(H, y1 + reach);
     const size_t npx = (size_t)W * (size_t)(ry1 - ry0);
     // the stream call_begin() will give this frame (it is self-contained: its planes are this stream's own)
-    Ctx::DofPlanes &D = g.dof[g.in_flight == 2 ? (g.last_stream ^ 1) : 0];
+    Ctx::DofPlanes &D = g.dof[next_si()];
     if (npx > D.cap_px) {
         for (void **p : { (void **)&D.rgb, (void **)&D.fd, (void **)&D.xrgb, (void **)&D.index, (void **)&D.zinv }) {
             if (*p) (void)hipFree(*p);
@@ -1168,22 +1213,22 @@ extern "C" int mirt_init(int device)
         return fail(MIRT_ERR_NO_DEVICE, "device %d is %s; the kernels in this library are built for gfx950 (MI355X) only", device, prop.gcnArchName);
     HIP_TRY(hipSetDevice(device));
     g.cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamCreateWithFlags(&g.streams[i], hipStreamNonBlocking));
+    for (int i = 0; i < MAX_FLIGHT; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&g.streams[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_order[i], hipEventDisableTiming));
+    }
     g.stream = g.streams[0];
     g.in_flight = 1;
     g.frame_no = 0;
-    g.last_stream = 1;
-    g.last_self_contained = false;
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_chain, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&g.ev_cull, hipEventDisableTiming));
-    for (int si = 0; si < 2; si++) for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev_sets[si][i]));
+    g.si = 0;
+    for (int si = 0; si < MAX_FLIGHT; si++) for (int i = 0; i < EV_COUNT; i++) HIP_TRY(hipEventCreate(&g.ev_sets[si][i]));
     g.ev_cur = 0; g.ev = g.ev_sets[0]; g.ev_used = g.ev_used_sets[0];
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 2 * MAX_FLIGHT; i++) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_hits2[i]), sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));
         HIP_TRY(hipMemset(g.d_hits2[i], 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE));   // (mirt_init ends with a device sync)
         g.hits_clean[i] = true;
     }
-    for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_tile_tab[i]), sizeof(float4) * 64 * (12 + 3 * MIRT_MAX_LIGHTS)));
+    for (int i = 0; i < MAX_FLIGHT; i++) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_tile_tab[i]), sizeof(float4) * 64 * (12 + 3 * MIRT_MAX_LIGHTS)));
     g.d_hits = g.d_hits2[0];
     g.device = device;
     HIP_TRY(hipDeviceSynchronize());             // the null-stream fills above have landed before any stream of ours runs
@@ -1195,30 +1240,31 @@ extern "C" void mirt_shutdown(void)
 {
     if (!g.init) return;
     (void)hipSetDevice(g.device);
-    for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
+    for (int i = 0; i < MAX_FLIGHT; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
     for (RtScratch &S : g.rt)
-        for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_light_rows, (void *)S.d_bin_off,
-                         (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, S.d_sort_temp, (void *)S.d_tmp_vals, (void *)S.d_bucket })
+        for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_light_rows, (void *)S.d_order, (void *)S.d_bin_off,
+                         (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, (void *)S.d_tmp_vals, (void *)S.d_bucket })
             if (p) (void)hipFree(p);
     for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }
-    for (void *p : { (void *)g.d_geo, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
+    for (void *p : { (void *)g.d_geo, (void *)g.d_shade, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
         if (p) (void)hipFree(p);
-    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, (void *)g.d_hits2[0], (void *)g.d_hits2[1], (void *)g.d_hits2[2], (void *)g.d_hits2[3], (void *)g.d_tile_tab[0], (void *)g.d_tile_tab[1], g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos, g.d_async[0], g.d_async[1],
-                     (void *)g.dof[0].rgb, (void *)g.dof[0].fd, (void *)g.dof[0].xrgb, (void *)g.dof[0].index, (void *)g.dof[0].zinv,
-                     (void *)g.dof[1].rgb, (void *)g.dof[1].fd, (void *)g.dof[1].xrgb, (void *)g.dof[1].index, (void *)g.dof[1].zinv })
+    for (void *p : { (void *)g.d_tris, (void *)g.d_culled, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos })
         if (p) (void)hipFree(p);
+    for (unsigned long long *p : g.d_hits2) if (p) (void)hipFree(p);
+    for (float4 *p : g.d_tile_tab) if (p) (void)hipFree(p);
+    for (void *p : g.d_async) if (p) (void)hipFree(p);
+    for (Ctx::DofPlanes &D : g.dof)
+        for (void *p : { (void *)D.rgb, (void *)D.fd, (void *)D.xrgb, (void *)D.index, (void *)D.zinv }) if (p) (void)hipFree(p);
     for (Ctx::HostSurface &r : g.surf) if (r.host) (void)hipHostUnregister(r.host);
     if (g.comm_stream) (void)hipStreamSynchronize(g.comm_stream);
     comm_destroy(g.comm);
     for (int i = 0; i < 2; i++) { if (g.d_band[i]) (void)hipFree(g.d_band[i]); if (g.ev_sent[i]) (void)hipEventDestroy(g.ev_sent[i]); }
     if (g.ev_rendered) (void)hipEventDestroy(g.ev_rendered);
     if (g.comm_stream) (void)hipStreamDestroy(g.comm_stream);
-    raster_scratch_free(g.raster[0]);
-    raster_scratch_free(g.raster[1]);
-    for (int si = 0; si < 2; si++) for (int i = 0; i < EV_COUNT; i++) if (g.ev_sets[si][i]) { (void)hipEventDestroy(g.ev_sets[si][i]); g.ev_sets[si][i] = nullptr; }
-    if (g.ev_chain) (void)hipEventDestroy(g.ev_chain);
-    if (g.ev_cull) (void)hipEventDestroy(g.ev_cull);
-    for (int i = 0; i < 2; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
+    for (RasterScratch &R : g.raster) raster_scratch_free(R);
+    for (int si = 0; si < MAX_FLIGHT; si++) for (int i = 0; i < EV_COUNT; i++) if (g.ev_sets[si][i]) { (void)hipEventDestroy(g.ev_sets[si][i]); g.ev_sets[si][i] = nullptr; }
+    for (hipEvent_t e : g.ev_order) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < MAX_FLIGHT; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
     g = Ctx();
 }
 
@@ -1259,17 +1305,19 @@ extern "C" int mirt_set_frames_in_flight(int frames)
 {
     int rc;
     if ((rc = need_init())) return rc;
-    if (frames < 1 || frames > 2) return fail(MIRT_ERR_INVALID_ARGUMENT, "frames in flight must be 1 or 2, not %d", frames);
+    if (frames < 1 || frames > MAX_FLIGHT) return fail(MIRT_ERR_INVALID_ARGUMENT, "frames in flight must be 1 .. %d, not %d", MAX_FLIGHT, frames);
     HIP_TRY(sync_all());
-    if (g.d_culled && g.n > 0) {                 // both halves of the cull flags start from the most recent ones
-        const size_t from = (size_t)g.culled_latest * g.n, to = (size_t)(g.culled_latest ^ 1) * g.n;
-        HIP_TRY(hipMemcpy(g.d_culled + to, g.d_culled + from, (size_t)g.n, hipMemcpyDeviceToDevice));
-        HIP_TRY(hipDeviceSynchronize());         // (null-stream copy: landed before a frame on one of our streams reads the flags)
+    if (g.d_culled && g.n > 0) {                 // every stream's copy of the cull flags starts from the most recent ones
+        for (int h = 0; h < MAX_FLIGHT; h++)
+            if (h != g.culled_latest) {
+                HIP_TRY(hipMemcpy(g.d_culled + (size_t)h * g.n, g.d_culled + (size_t)g.culled_latest * g.n, (size_t)g.n, hipMemcpyDeviceToDevice));
+                g.culled_ver[h] = g.culled_ver[g.culled_latest];
+            }
+        HIP_TRY(hipDeviceSynchronize());         // (null-stream copies: landed before a frame on one of our streams reads the flags)
     }
     g.in_flight = frames;
+    g.si = frames - 1;                           // the first call takes streams[0]
     g.stream = g.streams[0];
-    g.last_stream = 1;                       // the first overlapping frame takes streams[0]
-    g.last_self_contained = false;
     return MIRT_OK;
 }
 
@@ -1318,18 +1366,21 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     HIP_TRY(sync_all());
     g.n = 0;
     if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
-    if ((rc = dev_realloc(&g.d_culled, (size_t)2 * n))) return rc;
+    if ((rc = dev_realloc(&g.d_culled, (size_t)MAX_FLIGHT * n))) return rc;
     for (RtScratch &S : g.rt) { S.bin_key_valid = false; S.have_known = false; S.count_pending = false; }   // tables and pair counts belong to the old scene
     HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
-    for (int h = 0; h < 2; h++) {
+    g.cull_calls++;
+    for (int h = 0; h < MAX_FLIGHT; h++) {
         if (culled) HIP_TRY(hipMemcpy(g.d_culled + (size_t)h * n, culled, (size_t)n, hipMemcpyHostToDevice));
         else HIP_TRY(hipMemset(g.d_culled + (size_t)h * n, 0, (size_t)n));
+        g.culled_ver[h] = g.cull_calls;
     }
     if ((rc = dev_realloc(&g.d_geo, (size_t)n))) return rc;
+    if ((rc = dev_realloc(&g.d_shade, (size_t)n))) return rc;
     // the copies and fills above ran on the null stream, which the library's non-blocking streams are not ordered with (and a
     // copy from pageable memory may return once the source has been staged): everything has landed before a kernel reads it
     HIP_TRY(hipDeviceSynchronize());
-    hipLaunchKernelGGL(k_geo_table, dim3((n + 255) / 256), dim3(256), 0, g.stream, g.d_tris, n, g.d_geo);
+    hipLaunchKernelGGL(k_geo_table, dim3((n + 255) / 256), dim3(256), 0, g.stream, g.d_tris, n, g.d_geo, g.d_shade);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g.stream));
     g.lc.valid = false;
@@ -1354,9 +1405,11 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
     if (g.n <= 0) return fail(MIRT_ERR_NO_SCENE, "no scene uploaded (mirt_scene_upload)");
     if (n != g.n) return fail(MIRT_ERR_INVALID_ARGUMENT, "cull array has %d entries, scene has %d triangles", n, g.n);
     HIP_TRY(sync_all());
-    for (int h = 0; h < 2; h++) {
+    g.cull_calls++;
+    for (int h = 0; h < MAX_FLIGHT; h++) {
         if (culled) HIP_TRY(hipMemcpyAsync(g.d_culled + (size_t)h * n, culled, (size_t)n, hipMemcpyHostToDevice, g.stream));
         else HIP_TRY(hipMemsetAsync(g.d_culled + (size_t)h * n, 0, (size_t)n, g.stream));
+        g.culled_ver[h] = g.cull_calls;
     }
     HIP_TRY(hipStreamSynchronize(g.stream));
     g.cull_version++;
@@ -1373,15 +1426,19 @@ extern "C" int mirt_cull_device(const mirt_view *view, int flags)
     if (view->width <= 0 || view->height <= 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "frame %d x %d", view->width, view->height);
     CullParams cp;
     cull_setup(view, flags, &cp);
-    // The flags belong to the NEXT frame (the reference culls in Update(), right before Draw()): with two frames in flight
-    // they go into the half of d_culled that belongs to the stream that frame will take, on that stream, in order in front of
-    // it -- the frame still running on the other stream keeps its own flags, nothing waits for anything.
-    const int half = (g.in_flight == 2) ? (g.last_stream ^ 1) : 0;
-    hipStream_t st = (g.in_flight == 2) ? g.streams[half] : g.stream;
+    // The flags belong to the NEXT rasterised frame (the reference culls in Update(), right before Draw()): with several frames
+    // in flight they go into the copy of d_culled that belongs to the stream the next call will take, on that stream, in order
+    // in front of it -- the frames still running on the other streams keep their own flags, nothing waits for anything.  Should
+    // the next rasterised frame land on another stream after all (a ray-traced frame came in between), raster_enqueue brings
+    // the flags over (culled_ver tells).
+    const int half = next_si();
+    hipStream_t st = g.streams[half];
     (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (see call_begin)
     hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.d_tris, g.n, cp, g.d_culled + (size_t)half * g.n);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g.ev_order[half], st));
     g.culled_latest = half;
+    g.culled_ver[half] = ++g.cull_calls;
     g.cull_version++;
     return MIRT_OK;
 }
@@ -1503,7 +1560,7 @@ static int async_plane(size_t px, void **plane)
             if (hipMalloc(&p, px * 4) != hipSuccess) { p = nullptr; return fail(MIRT_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) for an asynchronous frame", px * 4); }
         g.async_cap_px = px;
     }
-    *plane = g.d_async[g.async_no++ & 1];
+    *plane = g.d_async[next_si()];                           // the plane of the stream this frame is about to take
     return MIRT_OK;
 }
 
@@ -1550,15 +1607,23 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
 
     // A rasteriser frame touches the scene (read only) and its stream's own scratch and depth-of-field planes, so frames
     // may overlap (call_begin).
-    call_begin(true);
-    RasterScratch &scratch = g.raster[(g.in_flight == 2 && g.stream == g.streams[1]) ? 1 : 0];
+    call_begin();
+    RasterScratch &scratch = g.raster[g.si];
+    if (g.culled_ver[g.si] != g.culled_ver[g.culled_latest]) {
+        // the most recent cull flags sit in another stream's copy (mirt_cull_device wrote them for the call it expected next,
+        // and a ray-traced frame took that turn): bring them over, ordered after the cull kernel
+        const int from = g.culled_latest;
+        HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_order[from], 0));
+        HIP_TRY(hipMemcpyAsync(g.d_culled + (size_t)g.si * g.n, g.d_culled + (size_t)from * g.n, (size_t)g.n, hipMemcpyDeviceToDevice, g.stream));
+        g.culled_ver[g.si] = g.culled_ver[from];
+    }
     g.pending_is_rt = false;
     if (y1 == y0) { call_end(); return MIRT_OK; }
 
     RasterFrame f;
     memset(&f, 0, sizeof f);
     f.tris15 = g.d_tris;
-    f.culled = g.d_culled + ((g.in_flight == 2 && g.stream == g.streams[1]) ? (size_t)g.n : 0);
+    f.culled = g.d_culled + (size_t)g.si * g.n;
     f.n = g.n;
     memcpy(f.cam, view->pos, 12);
     memcpy(f.rot, view->rot, 36);
@@ -1663,10 +1728,23 @@ extern "C" int mirt_get_stats(mirt_stats *out)
         } else if (g.pending_is_rt) {
             static unsigned long long shard[HIT_SHARDS * HIT_SHARD_STRIDE];
             HIP_TRY(hipMemcpy(shard, g.d_hits, sizeof shard, hipMemcpyDeviceToHost));
-            unsigned long long hits = 0, tests = 0, cands = 0;
-            for (int i = 0; i < HIT_SHARDS; i++) { hits += shard[i * HIT_SHARD_STRIDE]; tests += shard[i * HIT_SHARD_STRIDE + 1]; cands += shard[i * HIT_SHARD_STRIDE + 2]; }
+            unsigned long long hits = 0, tests = 0, cands = 0, sp = 0, ss = 0, dr = 0;
+            for (int i = 0; i < HIT_SHARDS; i++) {
+                const unsigned long long *w = shard + i * HIT_SHARD_STRIDE;
+                hits += w[0]; tests += w[1]; cands += w[2]; sp += w[3]; ss += w[4]; dr += w[5];
+            }
             g.stats.tests = tests;
             g.stats.candidates = cands;
+            g.stats.steps_primary = sp; g.stats.steps_shadow = ss; g.stats.drains = dr;
+            if (getenv("MIRT_TR_TIMING_DUMP")) {
+                unsigned long long seg[11] = { 0 };
+                for (int i = 0; i < HIT_SHARDS; i++) {
+                    for (int k = 0; k < 10; k++) seg[k] += shard[i * HIT_SHARD_STRIDE + 3 + k];
+                    seg[10] = std::max(seg[10], shard[i * HIT_SHARD_STRIDE + 13]);
+                }
+                fprintf(stderr, "[mirt timing] Mticks: record %.1f | stage %.1f steps %.1f drains %.1f merge %.1f | light term %.1f offsets+first row %.1f walk %.1f drain %.1f | rest %.1f | longest wave %llu ticks\n",
+                        seg[0] * 1e-6, seg[1] * 1e-6, seg[2] * 1e-6, seg[3] * 1e-6, seg[4] * 1e-6, seg[5] * 1e-6, seg[6] * 1e-6, seg[7] * 1e-6, seg[8] * 1e-6, seg[9] * 1e-6, seg[10]);
+            }
             g.stats.primary_rays = g.pending_primary;
             g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
             if (g.stats.mode_used == MIRT_RT_BRUTE && !g.pending_counted)      // every ray tests every triangle
@@ -1687,9 +1765,9 @@ extern "C" int mirt_get_previous_kernel_ms(float *kernel_ms8, float *gpu_ms)
     int rc;
     if ((rc = need_init())) return rc;
     if (!kernel_ms8) return fail(MIRT_ERR_INVALID_ARGUMENT, "kernel_ms8 must not be NULL");
-    if (g.in_flight != 2) return fail(MIRT_ERR_INVALID_ARGUMENT, "the call before the last one keeps its events only with mirt_set_frames_in_flight(2)");
+    if (g.in_flight < 2) return fail(MIRT_ERR_INVALID_ARGUMENT, "the call before the last one keeps its events only with two or more frames in flight (mirt_set_frames_in_flight)");
     HIP_TRY(sync_all());
-    const int set = g.ev_cur ^ 1;
+    const int set = (g.ev_cur + g.in_flight - 1) % g.in_flight;
     float ms = 0.0f;
     if (gpu_ms) *gpu_ms = (g.call_timed_sets[set] && hipEventElapsedTime(&ms, g.ev_sets[set][EV_CALL0], g.ev_sets[set][EV_CALL1]) == hipSuccess) ? ms : 0.0f;
     for (int k = 0; k < 8; k++) {

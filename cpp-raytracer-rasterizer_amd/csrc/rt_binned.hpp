@@ -61,6 +61,9 @@ __device__ __forceinline__ uint32_t bin_shell_of(const BinFrameDesc &fr, float n
 // Geometry row of a triangle: {v0.xyz, e1.x | e1.yz, e2.xy | e2.z, 0, 0, 0} -- what the accept path needs to rebuild the hit
 // point (raytracer.cpp:216-217, :241).  One per triangle (k_geo_table, rt_trace.hip).
 struct GeoRow { float4 g0, g1, g2; };
+// What shading needs of the closest triangle, as two 16-byte loads: glm::normalize(triangles[i].normal) (raytracer.cpp:300 -- per
+// triangle the same operands and operations as per pixel, so the same bits) and its colour.  One per triangle (k_geo_table).
+struct ShadeRow { float4 n, col; };
 // A shadow-ray candidate expanded in light-cube bin order: the origin row of the triangle for that light, with the triangle's
 // index in the one slot an origin row leaves free (r2.w, as bits) -- what the exact stage needs to find the geometry row.
 // (Round 2 first stored {origin row, geometry row}, 96 bytes: 250 MB of reads per 1080p frame of the 100 k soup, half of them

@@ -125,6 +125,18 @@ __device__ __forceinline__ void maybe_hit2(const TestDots2 &d, bool *m0, bool *m
     *m1 = fminf(fminf(a.y, b.y), slack.y) >= -2.384185791015625e-07f;
 }
 
+// The same filter as the quantity it thresholds: a ray may hit iff its half of the result is >= MAYBE_HIT_THRESHOLD (callers that
+// want the verdicts as wave masks compare it themselves).
+constexpr float MAYBE_HIT_THRESHOLD = -2.384185791015625e-07f;
+__device__ __forceinline__ f2 maybe_hit2_margin(const TestDots2 &d)
+{
+    const f2 s = { __uint_as_float((__float_as_uint(d.den.x) & 0x80000000u) | 0x3f800000u),
+                   __uint_as_float((__float_as_uint(d.den.y) & 0x80000000u) | 0x3f800000u) };
+    const f2 a = d.pu * s, b = d.qv * s, D = d.den * s;
+    const f2 slack = __builtin_elementwise_fma(D, splat2(1.00000095367431640625f), -(a + b));
+    return (f2){ fminf(fminf(a.x, b.x), slack.x), fminf(fminf(a.y, b.y), slack.y) };
+}
+
 // Dots and filter verdicts of P rays against one origin row: packed when P == 2 and the filter is on.
 template <int P, bool FILTER>
 __device__ __forceinline__ void test_rays(const float4 &r0, const float4 &r1, const float4 &r2, const v3 (&nd)[P],

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void k_prep_origin(const float *__restrict__ t
     if (blockIdx.y == 0 && blockIdx.x == 0) {
         if (zero_hits)
             for (int g = threadIdx.x; g < HIT_SHARDS * HIT_SHARD_STRIDE; g += blockDim.x) zero_hits[g] = 0ull;
-        if (zero_counter && threadIdx.x == 0) *zero_counter = 0u;
+        // [0] pairs of the binning pass, [16..23] tile pairs per list-length class (k_tile_order); the words between: debug statistics
+        if (zero_counter && (threadIdx.x == 0 || (threadIdx.x >= 16 && threadIdx.x < 24))) zero_counter[threadIdx.x] = 0u;
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int o = o0 + (int)blockIdx.y;
@@ -45,7 +46,6 @@ __global__ __launch_bounds__(256) void k_prep_origin(const float *__restrict__ t
 // The origin table is staged through LDS in chunks of CHUNK rows (48 B each); all 64 lanes read the same
 // row => three conflict-free ds_read_b128 broadcasts per triangle, reused for the lane's P rays.
 constexpr int RT_CHUNK = RT_CHUNK_ROWS;
-constexpr int GUARD_CHUNK = 128;            // origin rows per LDS chunk of k_rt_brute_guard
 
 // (bx, by) = the block of P*64 x 4 pixels; CHUNK = origin rows staged in LDS at a time
 template <int P, bool FILTER, bool AA, int CHUNK = RT_CHUNK>
@@ -543,22 +543,5 @@ __global__ __launch_bounds__(256) void k_rt_brute(const RtFrame f)
 
 template __global__ void k_rt_brute<1>(const RtFrame);
 template __global__ void k_rt_brute<2>(const RtFrame);
-
-// The safety net of a binned frame whose pair list was sized from an EARLIER frame's count (no read-back, no host sync): when
-// this frame's binning produced more pairs than the list holds (*pair_count > pair_cap; the sort and k_rt_trace then do
-// nothing) the frame is rendered by brute force -- every ray against every triangle, same filter, same exact arithmetic, same
-// bits -- otherwise every workgroup leaves at once.  The host learns the count a frame later and grows the list.
-__global__ __launch_bounds__(256) void k_rt_brute_guard(const RtFrame f, const uint32_t *__restrict__ pair_count, uint32_t pair_cap, int nbx, int nby)
-{
-    // A small resident grid striding over the frame's pixel blocks, with a small LDS slice: what matters is how quickly the
-    // launch leaves in the frame that did NOT overflow -- with one workgroup per block and 48 KB of LDS each, 4050 workgroups
-    // had to find room among the other stream's trace kernel first (12 us per frame on the 100 k soup).
-    __shared__ __attribute__((aligned(16))) float4 s_tab[GUARD_CHUNK * 3];
-    if (__builtin_amdgcn_readfirstlane(*pair_count) <= pair_cap) return;
-    for (int b = blockIdx.x; b < nbx * nby; b += gridDim.x) {
-        if (f.aa > 1) brute_body<2, true, true, GUARD_CHUNK>(f, s_tab, b % nbx, b / nbx);
-        else brute_body<2, true, false, GUARD_CHUNK>(f, s_tab, b % nbx, b / nbx);
-    }
-}
 
 }  // namespace mirt

@@ -1,28 +1,32 @@
-// rt_trace.hip -- the binned ray-trace kernel (k_rt_trace) and the tables it reads.
+// rt_trace.hip -- the binned ray-trace kernel (k_rt_trace2) and the tables it reads.
 //
 // Fused primary + shadow + shade + resolve over the binned candidates (rt_binned.hpp explains why the candidate
-// reduction cannot change any result).  Workgroup = 4 wave64, each wave owns one 8x8-pixel tile = one camera bin.
+// reduction cannot change any result).  Workgroup = 4 wave64 = a 32 x 16-pixel block; each wave owns TWO horizontally
+// adjacent 8 x 8-pixel tiles (= two camera bins), lane l carrying pixel (l & 7, l >> 3) of tile A and of tile B.
 //
-// What made the first version (k_rt_binned, round 1) slow, measured on the 100 k soup at 1080p (tools/soup_stats.py):
-// 139 VALU issue slots per ray-triangle test.  Nearly every candidate of a tile passes the conservative filter for SOME
-// lane, so the wave ran the exact path -- three IEEE divides, a gather of the triangle, a square root, ~100 instructions
-// -- once per candidate with one or two lanes active; and the shadow rays walked index lists with two dependent global
-// loads per step (latency-bound: 87 us for 6.3 M tests).  This kernel separates the two stages:
-//
-//   filter stage   every lane runs the 3 dot products + the 7-instruction filter of rt_common.hpp against the tile's
-//                  candidates (origin rows staged 64 at a time into the wave's LDS slice, broadcast reads); a (ray,
-//                  candidate) pair the filter cannot reject is APPENDED to a wave-private LDS queue -- v_mbcnt ranks
-//                  within the ballot, one ds_write_b128 {e1e2d, be2d, e1bd, e1e2b} + one ds_write_b64 {pixel, triangle};
-//   exact stage    whenever 64 pairs are queued the wave drains them with ALL lanes busy: lane t takes pair t, does the
-//                  reference's three divisions and accept test (raytracer.cpp:237-239), rebuilds the hit point from the
-//                  geometry row (:241-242) and folds the result into the pixel's record with an LDS atomic --
-//                  ds_min_u64 on the wavefront min-t key (distance bits << 32 | ~index: the `>=` tie rule of :243) for
-//                  primary rays, a plain flag store for shadow rays (any-hit is exact, SURVEY A-5).
-//
-// Shadow rays read EXPANDED rows: the light-cube bins only depend on the scene and the light, so they are built once per
-// (scene, lights) -- not per frame -- and stored bin-major as 48-byte origin rows with the triangle index in r2.w.  A lane walks
-// its bin sequentially (lanes of one bin share every address), the next row is requested while the current one is
-// tested, and nothing in the loop depends on an index load.
+// Round 2's kernel (one tile per wave, one ray per lane) spent 630 of its 1140 VALU instructions per wave on code that runs
+// once per tile whatever the lists hold -- ray set-up, the two partial drains, the light term with its square roots and
+// divisions, pack and store -- and walked each shadow ray through every triangle its light-cube bin holds, near or far.
+// This kernel
+//   * runs that per-tile code once per PAIR of tiles in packed FP32 (mirt_math2.hpp: v_pk_mul/add/fma round each half like
+//     their scalar twins; div2 shares the multiply-adds of two IEEE divisions);
+//   * filter stage, primary rays: the candidates of tile A and of tile B are staged INTERLEAVED in the wave's LDS slice
+//     ({A.x, B.x, A.y, B.y} ...), so one ds_read_b128 delivers the register pairs the packed dot products want: 15 packed
+//     instructions test candidate j of list A against pixel A and candidate j of list B against pixel B; a (ray, candidate)
+//     pair the 7-instruction filter of rt_common.hpp cannot reject is APPENDED to a wave-private LDS queue;
+//   * exact stage: whenever 64 pairs are queued the wave drains them with ALL lanes busy: lane t takes pair t, does the
+//     reference's three divisions and accept test (raytracer.cpp:237-239), rebuilds the hit point from the geometry row
+//     (:241-242) and folds the result into the pixel's record with an LDS atomic -- ds_min_u64 on the wavefront min-t key
+//     (distance bits << 32 | ~index: the `>=` tie rule of :243) for primary rays, a flag store for shadow rays (any-hit is
+//     exact, SURVEY A-5);
+//   * shadow rays: the light-cube bins are ordered by DEPTH SHELL of the candidates' `near` bound (sort key = bin * shells +
+//     shell), so a ray whose hit point lies at distance r from the light walks only the shells up to the one 0.99 r falls
+//     into -- every later candidate has near > 0.99 r and cannot occlude (:313).  A bin's list grows with the square of the
+//     distance from the light, so this drops most of it.  A lane walks the list of its pixel A and then that of its pixel B
+//     back to back (the wave's steps are max(lenA + lenB) over its lanes, not max(lenA) + max(lenB));
+//   * a frame whose pair list overflowed (sized from an earlier frame's count, mirt_capi.hip) is rendered by the SAME kernel
+//     with "every triangle" as each tile's list -- brute force, same bits -- instead of by a guard launch behind it;
+//   * workgroups are mapped to screen blocks so that the blocks an XCD (private L2) works on are neighbours.
 //
 // Same filter and the same exact arithmetic as every other kernel => bit-identical results.
 #include "rt_binned.hpp"
@@ -35,7 +39,7 @@ namespace mirt {
 
 // geo[t] = {v0.xyz, e1.x | e1.yz, e2.xy | e2.z, 0, 0, 0}: what the accept path needs to rebuild the hit point
 // pos = v0 + u*e1 + v*e2 (raytracer.cpp:216-217, :241).  Built once per scene upload.
-__global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tris15, int n, GeoRow *__restrict__ geo)
+__global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tris15, int n, GeoRow *__restrict__ geo, ShadeRow *__restrict__ shade)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -46,23 +50,29 @@ __global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tri
     g.g1 = make_float4(e1.y, e1.z, e2.x, e2.y);
     g.g2 = make_float4(e2.z, 0.0f, 0.0f, 0.0f);
     geo[t] = g;
+    const v3 nd = normalize3(ld3(t15 + 9));                                  // (:300)
+    ShadeRow sr;
+    sr.n = make_float4(nd.x, nd.y, nd.z, 0.0f);
+    sr.col = make_float4(t15[12], t15[13], t15[14], 0.0f);
+    shade[t] = sr;
 }
 
-// rows[p] = origin row of triangle entries[p] for the light its bin belongs to, with the triangle index in r2.w: the sorted
+// rows[p] = origin row of triangle entries[p] for the light its key belongs to, with the triangle index in r2.w: the sorted
 // pair list of the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.  bin_off points at the
-// first light bin (the pairs of bins in front of it -- a camera frame binned in the same pass -- are not light pairs);
-// bin_off[k * bins_per_light] is where the pairs of light k start.  pair_count / pair_cap (nullable): the pass that sized its
-// list from an earlier frame's count leaves its tables untouched when the list overflowed -- nothing to expand then.
+// first light key (the pairs of keys in front of it -- a camera frame binned in the same pass -- are not light pairs);
+// bin_off[k * keys_per_light] is where the pairs of light k start (keys_per_light = 6 * B * B * depth shells).  pair_count /
+// pair_cap (nullable): the pass that sized its list from an earlier frame's count leaves its tables untouched when the list
+// overflowed -- nothing to expand then.
 __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ entries,
-                                                           int nlights, uint32_t bins_per_light,
+                                                           int nlights, uint32_t keys_per_light,
                                                            const OriginRow *__restrict__ light_tab, int n,
                                                            LightRow *__restrict__ rows, const uint32_t *__restrict__ pair_count, uint32_t pair_cap)
 {
     if (pair_count && *pair_count > pair_cap) return;
-    const uint32_t first = bin_off[0], total = bin_off[(size_t)nlights * bins_per_light];
+    const uint32_t first = bin_off[0], total = bin_off[(size_t)nlights * keys_per_light];
     for (uint32_t p = first + blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
         int k = 0;
-        while (k + 1 < nlights && bin_off[(size_t)(k + 1) * bins_per_light] <= p) k++;
+        while (k + 1 < nlights && bin_off[(size_t)(k + 1) * keys_per_light] <= p) k++;
         const uint32_t tri = entries[p];
         LightRow r = light_tab[(size_t)k * n + tri];
         r.r2.w = __uint_as_float(tri);
@@ -74,26 +84,23 @@ __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__res
 #ifndef MIRT_TR_STAGE
 #define MIRT_TR_STAGE 16
 #endif
-#ifndef MIRT_TR_DRAIN
-#define MIRT_TR_DRAIN 64
-#endif
-// The kernel is latency-bound (dependent LDS / global round trips per candidate and per drain), so what a wave keeps in LDS
-// decides how many waves hide each other's latency: 64 staged candidates + hit points cost 8.4 KB per wave = 4 workgroups
-// per CU and 103 us on the 100 k soup; 16 staged candidates and (u, v) instead of the hit point: 5.4 KB, 7 workgroups, 84 us.
-constexpr int TR_STAGE = MIRT_TR_STAGE;          // candidates staged per chunk (at most one per lane)
-constexpr int TR_DRAIN = MIRT_TR_DRAIN;          // the exact stage runs when this many pairs are queued (<= 64)
-constexpr int TR_QUEUE = TR_DRAIN + 64;          // queue slots: fewer than TR_DRAIN pairs are queued when a filter step appends at most 64
-static_assert(TR_DRAIN >= 1 && TR_DRAIN <= 64, "a drain hands one pair to each lane");
+// What a wave keeps in LDS decides how many waves share a CU and hide each other's latencies (round 2: 8.4 -> 5.4 KB per
+// wave took the frame from 103 to 84 us): 16 staged candidates per tile, (u, v) instead of the hit point.
+constexpr int TR_STAGE = MIRT_TR_STAGE;          // candidates staged per chunk and tile (lanes 0..15 stage tile A's, 16..31 tile B's)
+constexpr int TR_DRAIN = 64;                     // the exact stage runs when this many pairs are queued: one pair per lane
+constexpr int TR_QUEUE = 128;                    // queue slots: fewer than TR_DRAIN are queued when a step appends (<= 64 per tile)
+constexpr int TR_PIX = 128;                      // pixels of a wave: tile A = 0..63, tile B = 64..127
+static_assert(TR_STAGE == 16, "the staging lanes are split 16 / 16 between the two tiles");
 
 struct TrWaveLds {
-    float4 rows[TR_STAGE * 3];        // origin rows of the staged candidates
+    float4 rows[TR_STAGE * 6];        // origin rows of the staged candidates, tile A's and tile B's interleaved float by float
+    float4 geo[TR_STAGE * 2 * 3];     // their geometry rows: slot = 16 * tile + position in the chunk
     float4 q[TR_QUEUE];               // {e1e2d, be2d, e1bd, e1e2b} of a queued (ray, candidate) pair
-    unsigned long long best[64];      // wavefront min-t key of the pixel's closest accepted hit (this sub-ray)
-    uint2 qa[TR_QUEUE];               // {pixel (lane) of the pair, triangle index | row index}
-    float2 uv[64];                    // (u, v) of the hit that belongs to best[]: the hit point is rebuilt from them (:241)
-    uint32_t idx[TR_STAGE];           // triangle ids of the staged candidates
-    float thr[64];                    // shadow rays: r * 0.99f (:313)
-    uint32_t flag[64];                // primary: some triangle was accepted (ClosestIntersection's return value); shadow: occluded
+    unsigned long long best[TR_PIX];  // wavefront min-t key of the pixel's closest accepted hit (this sub-ray)
+    uint2 qa[TR_QUEUE];               // {pixel of the pair | staging slot of its candidate << 8 (primary rays), triangle index}
+    float px[TR_PIX], py[TR_PIX], pz[TR_PIX];   // the hit point that belongs to best[] (:241)
+    float thr[TR_PIX];                // shadow rays: r * 0.99f (:313)
+    uint32_t flag[TR_PIX];            // primary: some triangle was accepted (ClosestIntersection's return value); shadow: occluded
 };
 static_assert(sizeof(TrWaveLds) % 16 == 0, "per-wave LDS slice must keep 16-byte alignment");
 
@@ -105,18 +112,27 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The exact stage for queue slots [0, count): raytracer.cpp:237-247.  geo + index * stride16 float4 = the pair's geometry row.
+// The exact stage for queue slots [0, count): raytracer.cpp:237-247.  The pair's geometry row: shadow rays fetch it (geo + 3 *
+// triangle float4); primary rays find it in the wave's LDS slice, staged with the candidate's origin row -- no memory round
+// trip inside the drain (their queue never outlives the staged chunk).
 template <bool SHADOW>
-__device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, const float4 *__restrict__ geo, int stride16, v3 start)
+__device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, const float4 *__restrict__ geo, v3 start)
 {
     wave_lds_fence();
     if (lane < count) {
         const float4 e = s.q[lane];
-        const uint2 a = s.qa[lane];
+        uint2 a = s.qa[lane];
         const float t = e.w / e.x, u = e.y / e.x, v = e.z / e.x;                     // :237
         if (u + v <= 1.0f && u >= 0.0f && v >= 0.0f && t >= 0.0f) {                  // :239
-            const float4 *g = geo + (size_t)a.y * stride16;
-            const float4 g0 = g[0], g1 = g[1], g2 = g[2];
+            float4 g0, g1, g2;
+            if (SHADOW) {
+                const float4 *g = geo + (size_t)a.y * 3;
+                g0 = g[0]; g1 = g[1]; g2 = g[2];
+            } else {
+                const float4 *g = s.geo + (a.x >> 8) * 3;
+                g0 = g[0]; g1 = g[1]; g2 = g[2];
+                a.x &= 0xFFu;
+            }
             const v3 v0 = V3(g0.x, g0.y, g0.z), e1 = V3(g0.w, g1.x, g1.y), e2 = V3(g1.z, g1.w, g2.x);
             const v3 p = add3(add3(v0, scale3(e1, u)), scale3(e2, v));              // :241
             const float dist = distance3(start, p);                                  // :242
@@ -129,7 +145,7 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
                 // the pair that holds the record now also owns the stored hit point (keys are unique per pixel: one
                 // pair per triangle); a closer pair of a later drain overwrites both
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (s.best[a.x] == key) s.uv[a.x] = make_float2(u, v);
+                if (s.best[a.x] == key) { s.px[a.x] = p.x; s.py[a.x] = p.y; s.pz[a.x] = p.z; }
             }
         }
     }
@@ -138,9 +154,9 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
 
 // Drains TR_DRAIN pairs and moves the rest of the queue to its front.
 template <bool SHADOW>
-__device__ __forceinline__ void tr_drain_full(TrWaveLds &s, int lane, int &qn, const float4 *__restrict__ geo, int stride16, v3 start)
+__device__ __forceinline__ void tr_drain_full(TrWaveLds &s, int lane, int &qn, const float4 *__restrict__ geo, v3 start)
 {
-    tr_drain<SHADOW>(s, lane, TR_DRAIN, geo, stride16, start);
+    tr_drain<SHADOW>(s, lane, TR_DRAIN, geo, start);
     const int rest = qn - TR_DRAIN;
     float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint2 a = make_uint2(0u, 0u);
@@ -151,208 +167,468 @@ __device__ __forceinline__ void tr_drain_full(TrWaveLds &s, int lane, int &qn, c
     wave_lds_fence();
 }
 
+// the wave's mask of a predicate, straight from the compare (__ballot goes through a 0/1 VGPR and a second compare)
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+__device__ __forceinline__ int wave_rank(unsigned long long m)      // lanes below this one that are set in m
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// cube_bin_of (rt_binned.hpp) for the two shadow rays of a lane: the same selections and the same operations per half, the
+// four divisions as two packed pairs (div2 rounds each half like `/`).
+__device__ __forceinline__ void cube_bin_of2(const v3p &rd, uint32_t face_base0, int cube_bins, uint32_t *bin0, uint32_t *bin1)
+{
+    f2 a, b, m;
+    int face[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const float x = h ? rd.x.y : rd.x.x, y = h ? rd.y.y : rd.y.x, z = h ? rd.z.y : rd.z.x;
+        const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+        int k;
+        float mm, aa, bb, sgn;
+        if (ax >= ay && ax >= az) { k = 0; mm = ax; sgn = x; aa = y; bb = z; }
+        else if (ay >= az) { k = 1; mm = ay; sgn = y; aa = z; bb = x; }
+        else { k = 2; mm = az; sgn = z; aa = x; bb = y; }
+        face[h] = 2 * k + (sgn < 0.0f ? 1 : 0);
+        if (h) { a.y = aa; b.y = bb; m.y = mm; } else { a.x = aa; b.x = bb; m.x = mm; }
+    }
+    // u, v in [-1,1]; NaN (degenerate ray, never accepted by any triangle) falls into bin 0
+    const f2 u = div2(a, m), v = div2(b, m);
+    const float half = 0.5f * (float)cube_bins;
+    const uint32_t per_face = (uint32_t)(cube_bins * cube_bins);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const float uu = h ? u.y : u.x, vv = h ? v.y : v.x;
+        int i = (int)floorf((uu + 1.0f) * half);
+        int j = (int)floorf((vv + 1.0f) * half);
+        i = min(max(i, 0), cube_bins - 1);
+        j = min(max(j, 0), cube_bins - 1);
+        const uint32_t bin = face_base0 + (uint32_t)face[h] * per_face + (uint32_t)j * cube_bins + (uint32_t)i;
+        if (h) *bin1 = bin; else *bin0 = bin;
+    }
+}
+
+// A tile pair as the trace kernel's waves pick it up: the first tile's camera bin, where its list starts (the second tile's
+// follows it), and the two lengths.
+struct TilePairRec { uint32_t tile, beg, nA, nB; };
+constexpr int ORDER_CLASSES = 8;                 // classes of max(nA, nB) / ORDER_CLASS_STEP, the last one open-ended
+constexpr uint32_t ORDER_CLASS_STEP = 16;        // = TR_STAGE: a class is a number of staging chunks
+
 struct RtTraceFrame {
     RtFrame f;
-    const uint32_t *cam_off;          // camera bins (8x8-pixel tiles): first entry of each, nbins + 1
-    const uint32_t *cam_entries;      // triangle ids ordered by camera bin
+    const uint32_t *cam_off;          // camera bins (8x8-pixel tiles): first entry of each key, nbins * cam_shells + 1
+    const uint32_t *cam_entries;      // triangle ids ordered by camera key
     const GeoRow *geo;                // n geometry rows (k_geo_table)
-    const uint32_t *light_off;        // light-cube bins of all light positions: first row of each, nlights*6*B*B + 1
-    const LightRow *light_rows;       // expanded candidates ordered by light-cube bin (k_expand_light_rows)
+    const ShadeRow *shade;            // n shading rows (k_geo_table)
+    const uint32_t *light_off;        // light-cube keys of all light positions: first row of each, nlights*6*B*B*light_shells + 1
+    const LightRow *light_rows;       // expanded candidates ordered by light-cube key (k_expand_light_rows)
+    const BinFrameDesc *light_frames; // 6 per light position: the depth-shell parameters (the faces of a light share them)
     int tiles_x;                      // camera bins per row
     int cube_bins;                    // B: light-cube bins per face side
     int cam_shells;                   // depth shells per camera bin: bin b's list is cam_off[b * cam_shells] .. cam_off[(b + 1) * cam_shells]
+    int light_shells;                 // depth shells per light-cube bin
     const uint32_t *pair_count;       // pairs this frame's binning produced / room in the pair list: beyond it the lists are
-    uint32_t pair_cap;                // incomplete, the kernel does nothing and k_rt_brute_guard renders the frame
+    uint32_t pair_cap;                // incomplete and every tile takes the whole triangle list instead (brute force)
+    const TilePairRec *order;         // the frame's tile pairs, longest lists first (k_tile_order): ORDER_CLASSES segments of npairs records
+    const uint32_t *order_count;      // records in each segment
+    uint32_t npairs;                  // tile pairs of the band = waves that have work
 };
 
+// One wave renders one PAIR of horizontally adjacent tiles.  Tiles differ a lot in what they cost -- on the 100 k soup 9 % of
+// them hold half of all candidates, ~90 each against an average of 14 -- and a wave that starts such a pair late is what the
+// whole launch then waits for (measured: the longest wave lives 60 us of a launch that would take 58 us with every wave slot
+// always full, and took 85).  k_tile_order therefore files the pairs by the length of their longer list into ORDER_CLASSES
+// classes, and wave w of the trace kernel takes the w-th record counting from the longest class: longest first, the
+// classic greedy schedule.  A record carries the pair's list bounds, so the wave's first load is its last indirection.
+// counters: [0] = pairs the binning pass produced (> pair_cap: the lists are incomplete, the frame is brute force and every
+// record goes to class 0), [16 + c] = records in class c (zeroed by k_prep_origin).
+__global__ __launch_bounds__(256) void k_tile_order(const uint32_t *__restrict__ cam_off, int cam_shells, int tiles_x, int j0, int j1,
+                                                    uint32_t *__restrict__ counters, uint32_t pair_cap, TilePairRec *__restrict__ order)
+{
+    const int pairs_x = (tiles_x + 1) / 2, npairs = pairs_x * (j1 - j0);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    TilePairRec r = { 0u, 0u, 0u, 0u };
+    int cls = -1;
+    if (p < npairs) {
+        const int px = p % pairs_x, ty = j0 + p / pairs_x;
+        r.tile = (uint32_t)(ty * tiles_x + 2 * px);
+        cls = 0;
+        if (counters[0] <= pair_cap) {
+            const uint32_t b0 = cam_off[(size_t)r.tile * cam_shells], b1 = cam_off[(size_t)(r.tile + 1) * cam_shells];
+            r.beg = b0; r.nA = b1 - b0;
+            r.nB = 2 * px + 1 < tiles_x ? cam_off[(size_t)(r.tile + 2) * cam_shells] - b1 : 0u;
+            cls = (int)min(max(r.nA, r.nB) / ORDER_CLASS_STEP, (uint32_t)(ORDER_CLASSES - 1));
+        }
+    }
+    // one atomic per (wave, class present): a class counter bumped once per record would serialise ~7 ns apiece
+#pragma unroll
+    for (int c = 0; c < ORDER_CLASSES; c++) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+        if (!m) continue;
+        uint32_t base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&counters[16 + c], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+        if (cls == c) order[(size_t)c * npairs + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+    }
+}
+
+#ifndef MIRT_TR_WAVES
+#define MIRT_TR_WAVES 4
+#endif
 template <bool AA>
-__global__ __launch_bounds__(256) void k_rt_trace(const RtTraceFrame tf)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAVES, MIRT_TR_WAVES))) void k_rt_trace2(const RtTraceFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
     const RtFrame &f = tf.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     TrWaveLds &s = reinterpret_cast<TrWaveLds *>(s_all)[wave];
 
-    const int tx = (int)blockIdx.x * 2 + (wave & 1);
-    const int ty = f.y0 / BIN_TILE + (int)blockIdx.y * 2 + (wave >> 1);
-    const int x = tx * BIN_TILE + (lane & 7), y = ty * BIN_TILE + (lane >> 3);
-    const bool tile_ok = tx < tf.tiles_x && ty * BIN_TILE < f.y1;
-    const bool ok = tile_ok && x < f.W && y >= f.y0 && y < f.y1;
-    if (!tile_ok) return;                                  // wave-uniform
-    if (__builtin_amdgcn_readfirstlane(*tf.pair_count) > tf.pair_cap) return;
+    // Wave -> tile pair: record w of k_tile_order's list, longest lists first.  (Waves never synchronise with each other, so a
+    // workgroup is just a scheduling unit of 1, 2 or 4 of them.)
+    uint32_t w = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
+    if (w >= tf.npairs) return;
+    TilePairRec rec = { 0u, 0u, 0u, 0u };
+    {
+        bool found = false;
+#pragma unroll
+        for (int c = ORDER_CLASSES - 1; c >= 0; c--) {
+            const uint32_t cnt = tf.order_count[c];
+            if (!found && w < cnt) { rec = tf.order[(size_t)c * tf.npairs + w]; found = true; }
+            if (!found) w -= cnt;
+        }
+        if (!found) return;                                // (cannot happen: the classes hold npairs records)
+    }
+    rec.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.tile); rec.beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.beg);
+    rec.nA = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.nA); rec.nB = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.nB);
+    const int txA = (int)(rec.tile % (uint32_t)tf.tiles_x), ty = (int)(rec.tile / (uint32_t)tf.tiles_x);
+    const bool enB = txA + 1 < tf.tiles_x;
+    const int xA = txA * BIN_TILE + (lane & 7), xB = xA + BIN_TILE, y = ty * BIN_TILE + (lane >> 3);
+    const bool okY = y >= f.y0 && y < f.y1;
+    const bool okA = okY && xA < f.W, okB = enB && okY && xB < f.W;
+    const unsigned long long okmA = wballot(okA), okmB = wballot(okB);
+    const unsigned nokA = (unsigned)__popcll(okmA), nokB = (unsigned)__popcll(okmB);
+#ifdef MIRT_TR_TIMING
+    // (experiments) where a wave's lifetime goes: TM_SEG(i) adds the time since the previous stamp to segment i
+    const long long tm0 = __builtin_amdgcn_s_memtime();
+    long long tm_last = tm0, tm_seg[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define TM_SEG(i) { const long long now_ = __builtin_amdgcn_s_memtime(); tm_seg[i] += now_ - tm_last; tm_last = now_; }
+#else
+#define TM_SEG(i)
+#endif
+    // the pair list overflowed (it was sized from an earlier frame's count): no lists -- every tile takes every triangle
+    const bool brute = (uint32_t)__builtin_amdgcn_readfirstlane((int)*tf.pair_count) > tf.pair_cap;
     const v3 cam = ld3(f.cam);
     const int rs = AA ? f.aa : 1;                          // realSamples (:549-554); compile-time 1 without supersampling
 
-    const uint32_t cbin = (uint32_t)ty * (uint32_t)tf.tiles_x + (uint32_t)tx;
-    const uint32_t cbeg = tf.cam_off[(size_t)cbin * tf.cam_shells], cend = tf.cam_off[(size_t)(cbin + 1) * tf.cam_shells];
+    const uint32_t begA = rec.beg, begB = rec.beg + rec.nA;
+    const uint32_t nA = brute ? (uint32_t)f.n : rec.nA, nB = brute ? (enB ? (uint32_t)f.n : 0u) : rec.nB;
+    const uint32_t nmax = max(nA, nB);
     const float4 *geo4 = reinterpret_cast<const float4 *>(tf.geo);
-    const float4 *lrow4 = reinterpret_cast<const float4 *>(tf.light_rows);
+    TM_SEG(0)
 
-    float best_d = FLT_MAX;                                // Update() reset (:335-339), once per frame
-    int best_i = -1;
-    v3 pos = V3(0.0f, 0.0f, 0.0f), avg = V3(0.0f, 0.0f, 0.0f);
-    unsigned ntests = 0, ncand = 0;
+    float bdA = FLT_MAX, bdB = FLT_MAX;                    // Update() reset (:335-339), once per frame
+    int biA = -1, biB = -1;
+    v3 posA = V3(0.0f, 0.0f, 0.0f), posB = posA;
+    v3p avg = splat3(V3(0.0f, 0.0f, 0.0f));
+    unsigned ntests = 0, ncand = 0, nsteps_p = 0, nsteps_s = 0, ndrains = 0;     // wave-uniform counters
+    unsigned ncand_l = 0;                                  // per lane: shadow candidates offered
     int qn = 0;                                            // queued pairs (wave-uniform)
+    const float hw = (float)f.W / 2.0f, hh = (float)f.H / 2.0f;
 
-    float y1 = aa_start(y, rs);                            // :566-569
+    f2 y1 = splat2(aa_start(y, rs));                       // :566-569
     for (int z = 0; z < rs; z++) {
-        float x1 = aa_start(x, rs);                        // :573-576
+        f2 x1 = { aa_start(xA, rs), aa_start(xB, rs) };    // :573-576
         for (int z2 = 0; z2 < rs; z2++) {
             // d = (x1 - W/2, y1 - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
-            const v3 d = V3(x1 - (float)f.W / 2.0f, y1 - (float)f.H / 2.0f, f.focal);
-            const v3 nd = neg3(mat3_mul_vec(f.rot, d));
+            const v3p d = V3P(x1 - splat2(hw), y1 - splat2(hh), splat2(f.focal));
+            const v3p nd = neg3p(mat3_mul_vecp(f.rot, d));
 
-            // ---- primary ray: closest hit of THIS sub-ray among the tile's candidates ----
+            // ---- primary rays: closest hit of THIS sub-ray among the tiles' candidates ----
             // A candidate whose `near` bound (origin row r1.w: no hit point on it is closer to the camera) lies beyond the
             // sub-ray's current record cannot replace it, and the record already makes ClosestIntersection return true: the
-            // lane does not queue it; once it lies beyond the record of EVERY pixel of the tile the wave does not even run
-            // the filter.  The lists come roughly front to back (depth shells in the sort key), so after the first drains
-            // most of a list is skipped.  The records are only updated by drains, i.e. the bounds lag -- never the result.
-            s.best[lane] = MIN_T_NONE;
-            s.flag[lane] = 0u;
-            if (ok) ncand += cend - cbeg;
-            float lane_best = FLT_MAX;                     // distance of the sub-ray's record so far
-            float tile_best = FLT_MAX;                     // max of lane_best over the tile's pixels (wave-uniform)
-            for (uint32_t base = cbeg; base < cend; base += TR_STAGE) {
-                const int cnt = (int)min((uint32_t)TR_STAGE, cend - base);
+            // lane does not queue it; once it lies beyond the record of EVERY pixel of its tile the wave does not even run
+            // the filter on it.  The lists come roughly front to back (depth shells in the sort key), so after the first
+            // drains most of a list is skipped.  The records are only updated by drains, i.e. the bounds lag -- never the result.
+            s.best[lane] = MIN_T_NONE; s.best[lane + 64] = MIN_T_NONE;
+            s.flag[lane] = 0u; s.flag[lane + 64] = 0u;
+            ncand += nokA * nA + nokB * nB;
+            float lbA = FLT_MAX, lbB = FLT_MAX;            // distance of the sub-ray's record so far
+            float tbA = FLT_MAX, tbB = FLT_MAX;            // their maxima over the tile's pixels (wave-uniform)
+            for (uint32_t base = 0; base < nmax; base += TR_STAGE) {
+                const int cntA = (int)min((uint32_t)TR_STAGE, nA > base ? nA - base : 0u);
+                const int cntB = (int)min((uint32_t)TR_STAGE, nB > base ? nB - base : 0u);
                 wave_lds_fence();                          // the previous chunk's row reads are done
                 float my_near = 0.0f;
-                if (lane < cnt) {
-                    const uint32_t idx = tf.cam_entries[base + lane];
+                const int sh = lane >> 4, sj = lane & 15;  // lanes 0..15 stage tile A's candidates, 16..31 tile B's
+                const bool stage = lane < 32 && sj < (sh ? cntB : cntA);
+                if (stage) {
+                    const uint32_t idx = brute ? base + (uint32_t)sj : tf.cam_entries[(sh ? begB : begA) + base + (uint32_t)sj];
                     const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
-                    const float4 a1 = src[1];
-                    s.idx[lane] = idx;
-                    s.rows[3 * lane] = src[0];
-                    s.rows[3 * lane + 1] = a1;
-                    s.rows[3 * lane + 2] = src[2];
+                    const float4 a0 = src[0], a1 = src[1], a2 = src[2];
+                    const float4 *gsrc = geo4 + (size_t)idx * 3;
+                    float4 *gdst = s.geo + lane * 3;
+                    gdst[0] = gsrc[0]; gdst[1] = gsrc[1]; gdst[2] = gsrc[2];
+                    float *dst = reinterpret_cast<float *>(s.rows) + sj * 24 + sh;
+                    dst[0] = a0.x; dst[2] = a0.y; dst[4] = a0.z; dst[6] = a0.w;
+                    dst[8] = a1.x; dst[10] = a1.y; dst[12] = a1.z; dst[14] = a1.w;
+                    dst[16] = a2.x; dst[18] = a2.y; dst[20] = a2.z; dst[22] = __uint_as_float(idx);
                     my_near = a1.w;
                 }
                 wave_lds_fence();
-                unsigned long long pm = __ballot(lane < cnt && !(my_near > tile_best));
+                TM_SEG(1)
+                uint32_t pmA = (uint32_t)wballot(stage && sh == 0 && !(my_near > tbA)) & 0xFFFFu;
+                uint32_t pmB = (uint32_t)(wballot(stage && sh == 1 && !(my_near > tbB)) >> 16) & 0xFFFFu;
+                uint32_t pm = pmA | pmB;
                 while (pm) {
-                    const int j = __builtin_ctzll(pm);
-                    pm &= pm - 1ull;
-                    const float4 r0 = s.rows[3 * j], r1 = s.rows[3 * j + 1], r2 = s.rows[3 * j + 2];
-                    const TestDots td = test_dots(r0, r1, r2, nd);
-                    const bool live = ok && !(r1.w > lane_best);
-                    if (live) ntests++;
-                    const bool pass = live && maybe_hit(td);
-                    const unsigned long long m = __ballot(pass);
-                    if (m) {
-                        const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (pass) {
-                            s.q[at] = make_float4(td.den, td.pu, td.qv, r0.w);
-                            s.qa[at] = make_uint2((uint32_t)lane, s.idx[j]);
+                    const int j = __builtin_ctz(pm);
+                    pm &= pm - 1u;
+                    nsteps_p++;
+                    const float4 *R = s.rows + 6 * j;
+                    const float4 R0 = R[0], R1 = R[1], R2 = R[2], R3 = R[3], R4 = R[4], R5 = R[5];
+                    // e1e2d, be2d, e1bd (raytracer.cpp:232-234) of (pixel A, candidate j of list A) and (pixel B, candidate j of list B)
+                    TestDots2 td;
+                    td.den = (f2){ R0.x, R0.y } * nd.x + (f2){ R0.z, R0.w } * nd.y + (f2){ R1.x, R1.y } * nd.z;
+                    td.pu = (f2){ R2.x, R2.y } * nd.x + (f2){ R2.z, R2.w } * nd.y + (f2){ R3.x, R3.y } * nd.z;
+                    td.qv = (f2){ R4.x, R4.y } * nd.x + (f2){ R4.z, R4.w } * nd.y + (f2){ R5.x, R5.y } * nd.z;
+                    // the filter's verdicts and the `near` tests as wave masks straight from the compares, combined on the scalar unit
+                    const f2 fm = maybe_hit2_margin(td);
+                    const unsigned long long nearA = wballot(!(R3.z > lbA)), nearB = wballot(!(R3.w > lbB));
+                    const unsigned long long filtA = wballot(fm.x >= MAYBE_HIT_THRESHOLD), filtB = wballot(fm.y >= MAYBE_HIT_THRESHOLD);
+                    const unsigned long long liveA = ((pmA >> j) & 1u) ? (okmA & nearA) : 0ull, liveB = ((pmB >> j) & 1u) ? (okmB & nearB) : 0ull;
+                    const unsigned long long mA = liveA & filtA, mB = liveB & filtB;
+                    const bool passA = (mA >> lane) & 1ull, passB = (mB >> lane) & 1ull;
+                    ntests += (unsigned)__popcll(liveA) + (unsigned)__popcll(liveB);
+                    if (mA | mB) {
+                        const int cA = __popcll(mA), cB = __popcll(mB);
+                        if (qn + cA + cB > TR_QUEUE) { TM_SEG(2) tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; ndrains++; TM_SEG(3) }   // (rare: no room for this step)
+                        if (passA) {
+                            const int at = qn + wave_rank(mA);
+                            s.q[at] = make_float4(td.den.x, td.pu.x, td.qv.x, R1.z);
+                            s.qa[at] = make_uint2((uint32_t)lane | ((uint32_t)j << 8), __float_as_uint(R5.z));
                         }
-                        qn += __popcll(m);
+                        if (passB) {
+                            const int at = qn + cA + wave_rank(mB);
+                            s.q[at] = make_float4(td.den.y, td.pu.y, td.qv.y, R1.w);
+                            s.qa[at] = make_uint2(((uint32_t)lane + 64u) | ((uint32_t)(16 + j) << 8), __float_as_uint(R5.w));
+                        }
+                        qn += cA + cB;
                         if (qn >= TR_DRAIN) {
-                            do tr_drain_full<false>(s, lane, qn, geo4, 3, cam); while (qn >= TR_DRAIN);    // (one pass when TR_DRAIN == 64)
-                            lane_best = min_t_dist(s.best[lane]);
-                            tile_best = wave_max_f(ok ? lane_best : -FLT_MAX);
-                            pm &= __ballot(!(my_near > tile_best));
+                            TM_SEG(2)
+                            do { tr_drain_full<false>(s, lane, qn, geo4, cam); ndrains++; } while (qn >= TR_DRAIN);
+                            TM_SEG(3)
+                            lbA = min_t_dist(s.best[lane]); lbB = min_t_dist(s.best[lane + 64]);
+                            tbA = wave_max_f(okA ? lbA : -FLT_MAX); tbB = wave_max_f(okB ? lbB : -FLT_MAX);
+                            pmA &= (uint32_t)wballot(stage && sh == 0 && !(my_near > tbA));
+                            pmB &= (uint32_t)(wballot(stage && sh == 1 && !(my_near > tbB)) >> 16);
+                            pm &= pmA | pmB;
                         }
                     }
                 }
+                // the chunk's queued pairs are settled before the next chunk replaces the staged rows (their geometry lives there);
+                // the records they leave prune the next chunk
+                TM_SEG(2)
+                if (qn) {
+                    tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; ndrains++;
+                    if (base + TR_STAGE < nmax) {
+                        lbA = min_t_dist(s.best[lane]); lbB = min_t_dist(s.best[lane + 64]);
+                        tbA = wave_max_f(okA ? lbA : -FLT_MAX); tbB = wave_max_f(okB ? lbB : -FLT_MAX);
+                    }
+                }
+                TM_SEG(3)
             }
-            if (qn) { tr_drain<false>(s, lane, qn, geo4, 3, cam); qn = 0; }
             // ... merged into the pixel's running record exactly as the sequential `>=` sweep would (:243): the
             // sub-ray's best replaces the record when it is at least as close (a later sub-ray wins exact ties)
-            const unsigned long long skey = s.best[lane];
-            const bool any = s.flag[lane] != 0u;           // ClosestIntersection's return value
-            const float sd = min_t_dist(skey);
-            if (any && best_d >= sd) {
-                // the hit point, rebuilt as the exact stage built it: pos = v0 + u*e1 + v*e2 (:241) -- same operands, same bits
-                const float2 suv = s.uv[lane];
-                best_d = sd; best_i = min_t_index(skey);
-                const float4 *gw = geo4 + (size_t)best_i * 3;
-                const float4 g0 = gw[0], g1 = gw[1], g2 = gw[2];
-                pos = add3(add3(V3(g0.x, g0.y, g0.z), scale3(V3(g0.w, g1.x, g1.y), suv.x)), scale3(V3(g1.z, g1.w, g2.x), suv.y));
+            const unsigned long long keyA = s.best[lane], keyB = s.best[lane + 64];
+            const bool anyA = s.flag[lane] != 0u, anyB = s.flag[lane + 64] != 0u;     // ClosestIntersection's return value
+            if (anyA && bdA >= min_t_dist(keyA)) {
+                bdA = min_t_dist(keyA); biA = min_t_index(keyA);
+                posA = V3(s.px[lane], s.py[lane], s.pz[lane]);       // the hit point as the exact stage computed it (:241)
+            }
+            if (anyB && bdB >= min_t_dist(keyB)) {
+                bdB = min_t_dist(keyB); biB = min_t_index(keyB);
+                posB = V3(s.px[lane + 64], s.py[lane + 64], s.pz[lane + 64]);
             }
 
-            const bool hit = ok && any;
-            count_hits(f, (unsigned long long)__popcll(__ballot(hit)));
-            if (__ballot(hit)) {
-                const float *t = f.tris15 + (size_t)15 * (best_i >= 0 ? best_i : 0);
-                const v3 nDir = normalize3(ld3(t + 9));            // (:300)
-                const v3 tcol = ld3(t + 12);
-                v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
+            TM_SEG(4)
+            const bool hitA = okA && anyA, hitB = okB && anyB;
+            const unsigned long long hmA = wballot(hitA), hmB = wballot(hitB);
+            const unsigned nhits = (unsigned)(__popcll(hmA) + __popcll(hmB));
+            if (hmA | hmB) {
+                const ShadeRow *srA = tf.shade + (biA >= 0 ? biA : 0), *srB = tf.shade + (biB >= 0 ? biB : 0);
+                const float4 nA4 = srA->n, cA4 = srA->col, nB4 = srB->n, cB4 = srB->col;
+                const v3p pos = join3(posA, posB);
+                const v3p nDir = join3(V3(nA4.x, nA4.y, nA4.z), V3(nB4.x, nB4.y, nB4.z));   // glm::normalize(normal) (:300), per triangle
+                const v3p tcol = join3(V3(cA4.x, cA4.y, cA4.z), V3(cB4.x, cB4.y, cB4.z));
+                v3p result = splat3(V3(0.0f, 0.0f, 0.0f)), result2 = result;
                 for (int k = 0; k < f.nlights; k++) {
+                    // DirectLight's term before the shadow test (raytracer.cpp:294-304), both pixels at once
                     const v3 L = ld3(f.lpos[k]);
-                    v3 rd;
-                    float r;
-                    v3 D = light_term(f, k, pos, nDir, &rd, &r);
+                    const v3p Lp = splat3(L);
+                    const f2 r = distance3p(pos, Lp);
+                    const f2 A = { sphere_area(r.x), sphere_area(r.y) };
+                    const v3 P = ld3(f.lcol[k]);                   // lightColor / samples (:296), divided on the host
+                    const v3p rd = normalize3p(sub3p(Lp, pos));
+                    const v3p B = V3P(div2(splat2(P.x), A), div2(splat2(P.y), A), div2(splat2(P.z), A));
+                    const f2 dn = dot3p(rd, nDir);
+                    const f2 mx = { (dn.x < 0.0f) ? 0.0f : dn.x, (dn.y < 0.0f) ? 0.0f : dn.y };   // std::max(d, 0.0f)
+                    v3p D = scale3p(B, mx);
+                    const f2 thr = r * splat2(0.99f);              // (:313)
+                    TM_SEG(5)
                     wave_lds_fence();
-                    const float thr = r * 0.99f;                   // (:313)
-                    s.thr[lane] = thr;
-                    s.flag[lane] = 0u;
-                    uint32_t e = 0, end = 0;
-                    if (hit) {
-                        const uint32_t bin = cube_bin_of(rd, (uint32_t)k * 6u * (uint32_t)(tf.cube_bins * tf.cube_bins), tf.cube_bins);
-                        e = tf.light_off[bin]; end = tf.light_off[bin + 1];
+                    s.thr[lane] = thr.x; s.thr[lane + 64] = thr.y;
+                    s.flag[lane] = 0u; s.flag[lane + 64] = 0u;
+                    // the candidates of each shadow ray: the rows of its light-cube bin, shells 0 .. shell(0.99 r) -- a row of a
+                    // later shell has near > 0.99 r (bin_shell_of is monotone in its argument) and cannot occlude (:313)
+                    uint32_t eA = 0, endA = 0, eB = 0, endB = 0;
+                    const float4 *rows4;
+                    if (brute) {
+                        rows4 = reinterpret_cast<const float4 *>(f.light_tab + (size_t)k * f.n);
+                        if (hitA) endA = (uint32_t)f.n;
+                        if (hitB) endB = (uint32_t)f.n;
+                    } else {
+                        rows4 = reinterpret_cast<const float4 *>(tf.light_rows);
+                        uint32_t binA, binB;
+                        cube_bin_of2(rd, (uint32_t)k * 6u * (uint32_t)(tf.cube_bins * tf.cube_bins), tf.cube_bins, &binA, &binB);
+                        // (shell of 0.99 r: bin_shell_of's formula on wave-uniform parameters, loaded once per light)
+                        const BinFrameDesc *lf = tf.light_frames + 6 * k;
+                        const int ns = tf.light_shells;
+                        const float sd0 = lf->shell_d0, siw = lf->shell_iw;
+                        const uint32_t shA = ns > 1 ? (uint32_t)min(max((int)((thr.x - sd0) * siw), 0), ns - 1) : 0u;
+                        const uint32_t shB = ns > 1 ? (uint32_t)min(max((int)((thr.y - sd0) * siw), 0), ns - 1) : 0u;
+                        if (hitA) {
+                            const uint32_t key = binA * (uint32_t)ns;
+                            eA = tf.light_off[key]; endA = tf.light_off[key + shA + 1u];
+                        }
+                        if (hitB) {
+                            const uint32_t key = binB * (uint32_t)ns;
+                            eB = tf.light_off[key]; endB = tf.light_off[key + shB + 1u];
+                        }
                     }
+                    ncand_l += (endA - eA) + (endB - eB);
+                    // the lane walks list A, then list B
+                    const bool firstA = eA < endA;
+                    uint32_t e = firstA ? eA : eB, end = firstA ? endA : endB, pix = firstA ? (uint32_t)lane : (uint32_t)lane + 64u;
+                    v3 crd = firstA ? half0(rd) : half1(rd);
+                    float cthr = firstA ? thr.x : thr.y;
+                    bool pend = firstA && eB < endB;
                     bool act = e < end;
-                    ncand += end - e;
                     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0;
-                    if (act) { const float4 *src = lrow4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
-                    while (__ballot(act)) {
-                        // request the next row before this one is tested
-                        const bool nact = act && (e + 1 < end);
+                    if (act) { const float4 *src = rows4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
+                    TM_SEG(6)
+                    while (wballot(act)) {
+                        nsteps_s++;
+                        // request the next row before this one is tested: the next of this list, or the first of list B
+                        const bool cont = act && (e + 1 < end);
+                        const bool sw = act && !cont && pend;
+                        const uint32_t ne = cont ? e + 1 : eB;
+                        const bool nact = cont || sw;
                         float4 n0 = c0, n1 = c1, n2 = c2;
-                        if (nact) { const float4 *src = lrow4 + (size_t)(e + 1) * 3; n0 = src[0]; n1 = src[1]; n2 = src[2]; }
-                        const TestDots td = test_dots(c0, c1, c2, rd);           // negD = rDir (:310, :229)
+                        if (nact) { const float4 *src = rows4 + (size_t)ne * 3; n0 = src[0]; n1 = src[1]; n2 = src[2]; }
+                        const TestDots td = test_dots(c0, c1, c2, crd);          // negD = rDir (:310, :229)
                         // a candidate none of whose points is closer to the light than 0.99 r cannot occlude (:313)
-                        const bool pass = act && !(c1.w > thr) && maybe_hit(td);
-                        if (act) ntests++;
-                        const unsigned long long m = __ballot(pass);
+                        const bool pass = act && !(c1.w > cthr) && maybe_hit(td);
+                        ntests += (unsigned)__popcll(wballot(act));
+                        const unsigned long long m = wballot(pass);
                         bool occ = false;
                         if (m) {
-                            const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                             if (pass) {
+                                const int at = qn + wave_rank(m);
                                 s.q[at] = make_float4(td.den, td.pu, td.qv, c0.w);
-                                s.qa[at] = make_uint2((uint32_t)lane, __float_as_uint(c2.w));     // the candidate's triangle (r2.w)
+                                s.qa[at] = make_uint2(pix, brute ? e : __float_as_uint(c2.w));     // the candidate's triangle
                             }
                             qn += __popcll(m);
                             if (qn >= TR_DRAIN) {
-                                do tr_drain_full<true>(s, lane, qn, geo4, 3, L); while (qn >= TR_DRAIN);
-                                occ = s.flag[lane] != 0u;                        // a lane found occluded stops walking
+                                TM_SEG(7)
+                                do { tr_drain_full<true>(s, lane, qn, geo4, L); ndrains++; } while (qn >= TR_DRAIN);
+                                TM_SEG(8)
+                                occ = act && !sw && s.flag[pix] != 0u;           // found occluded: the rest of this list is moot
                             }
                         }
-                        c0 = n0; c1 = n1; c2 = n2;
-                        e++;
-                        act = nact && !occ;
+                        if (sw) { crd = half1(rd); cthr = thr.y; pix = (uint32_t)lane + 64u; end = endB; pend = false; }
+                        e = ne; c0 = n0; c1 = n1; c2 = n2;
+                        act = nact;
+                        if (wballot(occ)) {
+                            if (occ) {
+                                act = pend;
+                                if (pend) {                                      // on to list B (its first row was not requested ahead)
+                                    crd = half1(rd); cthr = thr.y; pix = (uint32_t)lane + 64u; e = eB; end = endB; pend = false;
+                                    const float4 *src = rows4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2];
+                                }
+                            }
+                        }
                     }
-                    if (qn) { tr_drain<true>(s, lane, qn, geo4, 3, L); qn = 0; }
-                    if (s.flag[lane] != 0u) D = V3(0.0f, 0.0f, 0.0f);           // occluded (:313-314); any-hit is exact
-                    result = add3(result, D);                      // (:319)
-                    if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // (:322) after each light's samples
+                    TM_SEG(7)
+                    if (qn) { tr_drain<true>(s, lane, qn, geo4, L); qn = 0; ndrains++; }
+                    TM_SEG(8)
+                    // occluded (:313-314); any-hit is exact
+                    if (s.flag[lane] != 0u) { D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f; }
+                    if (s.flag[lane + 64] != 0u) { D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f; }
+                    result = add3p(result, D);                     // (:319)
+                    if ((k + 1) % f.samples == 0) result2 = add3p(result2, result);   // (:322) after each light's samples
                 }
-                if (hit) {
-                    const v3 Dl = mul3(result2, tcol);             // (:325-326)
-                    const v3 T = add3(Dl, ld3(f.indirect));        // (:584-586)
-                    avg = add3(avg, mul3(tcol, T));                // (:587-591)
-                    x1 += aa_step(rs);                             // (:593) only after a hit
-                }
+                const v3p Dl = mul3p(result2, tcol);               // (:325-326)
+                const v3p shaded = add3p(avg, mul3p(tcol, add3p(Dl, splat3(ld3(f.indirect)))));   // (:584-591)
+                avg = join3(hitA ? half0(shaded) : half0(avg), hitB ? half1(shaded) : half1(avg));
+                if (AA) x1 = x1 + (f2){ hitA ? aa_step(rs) : 0.0f, hitB ? aa_step(rs) : 0.0f };   // (:593) only after a hit
+            }
+            // the frame's counters: hits (= shadow rays per light position), then the kernel's own statistics at the end
+            if (lane == 0 && nhits) {
+                const unsigned shard = (blockIdx.x + (threadIdx.x >> 6) * 61u) % HIT_SHARDS;
+                atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE, (unsigned long long)nhits);
             }
             wave_lds_fence();
         }
-        y1 += aa_step(rs);                                         // (:596)
+        if (AA) y1 = y1 + splat2(aa_step(rs));                     // (:596)
     }
-    count_tests(f, ntests);
-    count_candidates(f, ncand);
-    if (!ok) return;
-    avg = div3s(avg, (float)(rs * rs));                            // (:599)
-    const size_t px = (size_t)y * f.W + x;
-    if (f.rgb) st3(f.rgb + 3 * px, avg);
-    if (f.index) f.index[px] = best_i;
-    if (f.fd) f.fd[px] = best_i >= 0 ? best_d - f.focal_plane : 0.0f;          // focalDistances (:248-249)
-    store_intersection(f, px, best_i, best_d, pos);
-    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)            // (:618-620)
-        f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
+    {
+        // tests executed, candidates offered (list entries x rays), wave steps of the two filter loops, drains: one atomic
+        // instruction, lane i adding to word 1 + i of the wave's shard
+        ncand += wave_sum(ncand_l);
+        const unsigned shard = (blockIdx.x + (threadIdx.x >> 6) * 61u) % HIT_SHARDS;
+#ifdef MIRT_TR_TIMING
+        // (experiments) words 3..12 carry the segments' sums instead of the step counts, word 13 the longest lifetime
+        TM_SEG(9)
+        if (lane == 0) {
+            for (int i = 0; i < 10; i++) atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 3 + i, (unsigned long long)tm_seg[i]);
+            atomicMax(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 13, (unsigned long long)(tm_last - tm0));
+        }
+        const unsigned v = lane == 0 ? ntests : ncand;
+        if (lane < 2 && v) atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 1 + lane, (unsigned long long)v);
+#else
+        const unsigned v = lane == 0 ? ntests : lane == 1 ? ncand : lane == 2 ? nsteps_p : lane == 3 ? nsteps_s : ndrains;
+        if (lane < 5 && v) atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 1 + lane, (unsigned long long)v);
+#endif
+    }
+    if (AA) {                                                      // avgColor /= realSamples^2 (:599); /1 is the identity
+        const f2 q = splat2((float)(rs * rs));
+        avg = V3P(div2(avg.x, q), div2(avg.y, q), div2(avg.z, q));
+    }
+    if (okA) {
+        const v3 c = half0(avg);
+        const size_t px = (size_t)y * f.W + xA;
+        if (f.rgb) st3(f.rgb + 3 * px, c);
+        if (f.index) f.index[px] = biA;
+        if (f.fd) f.fd[px] = biA >= 0 ? bdA - f.focal_plane : 0.0f;            // focalDistances (:248-249)
+        store_intersection(f, px, biA, bdA, posA);
+        if (xA >= 1 && xA < f.W - 1 && y >= 1 && y < f.H - 1)      // (:618-620)
+            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + xA] = pack_xrgb(c);
+    }
+    if (okB) {
+        const v3 c = half1(avg);
+        const size_t px = (size_t)y * f.W + xB;
+        if (f.rgb) st3(f.rgb + 3 * px, c);
+        if (f.index) f.index[px] = biB;
+        if (f.fd) f.fd[px] = biB >= 0 ? bdB - f.focal_plane : 0.0f;
+        store_intersection(f, px, biB, bdB, posB);
+        if (xB >= 1 && xB < f.W - 1 && y >= 1 && y < f.H - 1)
+            f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + xB] = pack_xrgb(c);
+    }
 }
 
-template __global__ void k_rt_trace<false>(const RtTraceFrame);
-template __global__ void k_rt_trace<true>(const RtTraceFrame);
+template __global__ void k_rt_trace2<false>(const RtTraceFrame);
+template __global__ void k_rt_trace2<true>(const RtTraceFrame);
 
-size_t rt_trace_lds_bytes() { return 4 * sizeof(TrWaveLds); }
+size_t rt_trace_lds_bytes(int waves) { return (size_t)waves * sizeof(TrWaveLds); }
 
 }  // namespace mirt

@@ -41,7 +41,8 @@ class Light(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tests", C.c_uint64),
-                ("gpu_ms", C.c_float), ("kernel_ms", C.c_float * 8), ("mode_used", C.c_int32), ("candidates", C.c_uint64)]
+                ("gpu_ms", C.c_float), ("kernel_ms", C.c_float * 8), ("mode_used", C.c_int32), ("candidates", C.c_uint64),
+                ("steps_primary", C.c_uint64), ("steps_shadow", C.c_uint64), ("drains", C.c_uint64)]
 
 
 _vp = C.c_void_p
@@ -177,7 +178,8 @@ def stats():
     s = Stats()
     _check(load().mirt_get_stats(C.byref(s)))
     return {"primary_rays": s.primary_rays, "shadow_rays": s.shadow_rays, "tests": s.tests, "gpu_ms": s.gpu_ms,
-            "kernel_ms": dict(zip(KERNEL_NAMES, list(s.kernel_ms))), "mode_used": s.mode_used, "candidates": s.candidates}
+            "kernel_ms": dict(zip(KERNEL_NAMES, list(s.kernel_ms))), "mode_used": s.mode_used, "candidates": s.candidates,
+            "steps_primary": s.steps_primary, "steps_shadow": s.steps_shadow, "drains": s.drains}
 
 
 # ---- scene ------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define MIRT_API __attribute__((visibility("default")))
-#define MIRT_ABI_VERSION 2
+#define MIRT_ABI_VERSION 3
 #define MIRT_MAX_LIGHTS 32            /* Light lights[32], raytracer.cpp:48 / rasteriser.cpp:50 */
 
 typedef enum mirt_status {
@@ -80,6 +80,11 @@ typedef struct mirt_stats {
     int32_t mode_used;            /* mirt_rt_mode actually used                                      */
     uint64_t candidates;          /* ray-candidate pairs the frame's lists offered (>= tests: the binned kernel skips
                                      candidates that cannot matter before it tests them); == tests elsewhere */
+    /* the binned ray tracer's own loop counts (0 elsewhere): wave-level steps of the two filter loops -- one step = one
+     * candidate row tested by the lanes of a wave -- and exact-stage drains; what the kernel's instruction count scales with */
+    uint64_t steps_primary;
+    uint64_t steps_shadow;
+    uint64_t drains;
 } mirt_stats;
 
 /* indices into mirt_stats.kernel_ms */
@@ -103,15 +108,17 @@ MIRT_API int mirt_set_profiling(int on);
 /* Blocks until all work queued by the library has finished. */
 MIRT_API int mirt_sync(void);
 /* The library's hipStream_t (as void*), so a caller can order its own work around ours (wait for an event before a
- * call, record one after it).  With two frames in flight (below) it is the stream of the most recent call only:
+ * call, record one after it).  With several frames in flight (below) it is the stream of the most recent call only:
  * order with mirt_sync() instead. */
 MIRT_API void *mirt_stream(void);
-/* How many *_device frames may be in flight at once: 1 (default; calls run in order on one stream) or 2 (calls
- * alternate between two streams; the next frame is dispatched while the previous one drains, which hides the
- * dispatch gap between frames).  With 2 the caller must give consecutive frames DIFFERENT output planes -- the
- * double buffering a render loop that presents one frame while drawing the next already has (the reference's
- * SDL_UpdateRect after Draw(), raytracer.cpp:653) -- and mirt_sync() before reading them.  Every scratch buffer a frame
- * writes (origin and bin tables, raster keys, depth-of-field planes, counters) exists once per stream. */
+/* How many *_device frames may be in flight at once: 1 (default; calls run in order on one stream) up to 4 (calls take
+ * that many streams in turn; the next frames are dispatched, and run where the device has room, while the previous ones
+ * drain -- the kernels of a frame are short dependent chains, and several frames fill each other's gaps).  With k frames
+ * in flight the caller must give k consecutive frames DIFFERENT output planes -- the double (k-fold) buffering a render
+ * loop that presents one frame while drawing the next already has (the reference's SDL_UpdateRect after Draw(),
+ * raytracer.cpp:653); frames i and i + k share a stream and may share planes -- and mirt_sync() before reading them.
+ * Every scratch buffer a frame writes (origin and bin tables, raster keys, depth-of-field planes, counters) exists once
+ * per stream. */
 MIRT_API int mirt_set_frames_in_flight(int frames);
 
 /* ---- host surfaces --------------------------------------------------------------------------------- */
@@ -163,9 +170,10 @@ MIRT_API int mirt_cull(const float *tris15, int n, const mirt_view *view, int fl
 /* The same step on the device for the uploaded scene (one thread per triangle; the flags go straight into the scene's
  * device-side cull array, no host copy either way) -- what replaces the loop at rasteriser.cpp:404-447 once meshes are
  * large.  mirt_scene_get_culled reads the flags back (the reference's triangles[i].isCulled).  The flags are those of the
- * NEXT mirt_rasterise* call, as Update() culls right before Draw(): with mirt_set_frames_in_flight(2) they are written for,
- * and on, the stream that call takes, so the frame still running on the other stream keeps its own -- a frame drawn as
- * several calls (row bands) therefore culls before each of them. */
+ * NEXT mirt_rasterise* call(s), as Update() culls right before Draw(): with several frames in flight they are written for,
+ * and on, the stream the next call takes, so the frames still running on the other streams keep their own; a rasterised
+ * frame that lands on another stream (the second row band of a frame, or after a ray-traced frame took that turn) brings
+ * the most recent flags over, ordered behind the cull kernel. */
 MIRT_API int mirt_cull_device(const mirt_view *view, int flags);
 MIRT_API int mirt_scene_get_culled(uint8_t *culled, int n);
 /* LoadSTL::LoadSTLFile (rasteriser/Source/LoadSTL.cpp:17-97): reads an ASCII STL the way the reference does (every line
@@ -282,10 +290,10 @@ MIRT_API int mirt_rasterise_sharded(const mirt_view *views, int nviews, const mi
 
 /* Counters / timings of the most recent render call. */
 MIRT_API int mirt_get_stats(mirt_stats *out);
-/* With profiling on and two frames in flight: the per-kernel GPU times (kernel_ms8[8], indexed like mirt_stats.kernel_ms) and the
+/* With profiling on and two or more frames in flight: the per-kernel GPU times (kernel_ms8[8], indexed like mirt_stats.kernel_ms) and the
  * GPU time of the call BEFORE the last one -- the frame on the other stream, whose kernels ran while the frames on both sides of
  * it were running, which is the state a render loop is in.  (mirt_get_stats reports the last call, whose tail runs alone.)
- * Waits for both streams. */
+ * Waits for all streams. */
 MIRT_API int mirt_get_previous_kernel_ms(float *kernel_ms8, float *gpu_ms);
 
 #ifdef __cplusplus

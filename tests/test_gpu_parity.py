@@ -754,7 +754,7 @@ def test_two_frames_in_flight(oracle):
         for s in (sa, sb, sr):
             s.free()
     with pytest.raises(mirt.MirtError):
-        mirt.set_frames_in_flight(3)
+        mirt.set_frames_in_flight(5)
 
 
 def test_rt_binned_pair_list_grows(oracle, tmp_path):
@@ -1020,12 +1020,59 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_rt_binned_overflowed_guess_regrows_while_the_view_stands_still(tmp_path):
+    """Round-2 advisor finding: a guessed pair list that overflowed was never regrown while the view stayed the same (the
+    overflow frame made the view's binning 'known', later identical frames reused its too-small list and fell back to brute
+    force every time).  Here: view A (few pairs) sizes the list, then the camera jumps to view B (many pairs) and STAYS there:
+    frame B1 overflows (brute force inside k_rt_trace2, rays x triangles filter evaluations), and by the time its count has
+    reached the host a later frame of the same view must run binned again.  All frames equal brute force."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path[:0] = [%r, %r]
+import mirt
+from devbuf import DeviceArray
+mirt.init(0)
+L = np.zeros((0, 7), np.float32)                   # no light: camera-only binning passes, nothing else sizes the pair list
+W, H = 320, 200
+tris = mirt.scene_soup(8, 4000, 0.06)
+mirt.scene_upload(tris)
+far = [mirt.make_view((0.001 * i, 0, -40.0), mirt.rot_from_yaw(0.0, 1.0), 100.0, W, H) for i in range(6)]
+near = mirt.make_view((0.02, 0, -1.6), mirt.rot_from_yaw(0.01, 1.0), 1000.0, W, H)     # zoomed in: every triangle covers dozens of tiles
+def frame(v, mode):
+    b = DeviceArray((H, W), np.uint32, 0x21)
+    mirt.raytrace_device(v, L, (0.2, 0.2, 0.2), mode, 0, H, 0, b.ptr, W * 4)
+    st = mirt.stats()
+    return b.read(), st["tests"]
+want_near, _ = frame(near, mirt.RT_BRUTE)
+# six far views: the first pass is sized by a read-back, the others are guessed from the far counts (a few thousand pairs)
+for v in far:
+    frame(v, mirt.RT_BINNED)
+tests = []
+for i in range(5):
+    got, t = frame(near, mirt.RT_BINNED)           # (mirt.stats() waits for the frame: its count has reached the host by the next call)
+    assert np.array_equal(got, want_near), "near frame %%d differs" %% i
+    tests.append(t)
+assert tests[0] > 100 * tests[-1] > 0, tests         # the first one overflowed into brute force ...
+assert all(t < 2 * tests[-1] for t in tests[2:]), tests  # ... and from the third on the list has been regrown: binned again
+# (the order inside a bin's list is not deterministic, so the counts of identical binned frames differ by a little)
+mirt.shutdown()
+print("ok")
+""" % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-raytracer-rasterizer_amd"),
+       os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIRT_BIN_INITIAL_PAIRS="3000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_rt_binned_pair_list_guess_overflows_into_brute_force(oracle, tmp_path):
     """A moving camera sizes the binned path's pair list from the count of an EARLIER frame, without a read-back; when a frame
     produces more pairs than that (here: the camera jumps from far away to right in front of the soup, with a list that
-    starts at 1000 pairs) the sort and the trace kernel stand down and k_rt_brute_guard renders the frame -- it must equal
-    the brute-force frame, and the frames after it (list grown from the count learned meanwhile) as well.  In a child
-    process: the first capacity is read once per process."""
+    starts at 1000 pairs) the sort stands down and the trace kernel renders the frame with every triangle as each tile's list
+    (brute force inside k_rt_trace2) -- it must equal the brute-force frame, and the frames after it (list grown from the count
+    learned meanwhile) as well.  In a child process: the first capacity is read once per process."""
     import os
     import subprocess
     import sys
@@ -1052,13 +1099,13 @@ for v in views:
     mirt.raytrace_device(v, L, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, b.ptr, W * 4)
     st = mirt.stats()
     assert st["mode_used"] == mirt.RT_BINNED and st["shadow_rays"] > 0
-    filtered.append(st["tests"])                  # filter evaluations of k_rt_trace: none when the frame fell back to brute force
+    filtered.append(st["tests"])                  # filter evaluations of k_rt_trace2: rays x triangles when the frame fell back to brute force
     got.append(b.read())
 # The first pass of a kind (here: camera + the cube of a light not seen before) is sized by a read-back; the passes after it are
-# guessed from its count and -- MIRT_TEST_PAIR_CAP pretends a guessed list holds 2000 pairs -- overflow: k_rt_trace stands down
-# (no filter evaluations counted) and k_rt_brute_guard renders the frame.  The fifth frame finds its light unchanged for the
-# fourth time, builds the shared light cube and sizes its camera-only pass by a read-back again.
-assert filtered[0] > 0 and all(t == 0 for t in filtered[1:4]) and filtered[4] > 0, filtered
+# guessed from its count and -- MIRT_TEST_PAIR_CAP pretends a guessed list holds 2000 pairs -- overflow: k_rt_trace2 takes every
+# triangle for every tile (hundreds of times the filter evaluations of a binned frame).  The fifth frame finds its light unchanged
+# for the fourth time, builds the shared light cube and sizes its camera-only pass by a read-back again.
+assert filtered[0] > 0 and filtered[4] > 0 and all(t > 100 * filtered[4] for t in filtered[1:4]), filtered
 for i, (a, b) in enumerate(zip(got, want)):
     assert np.array_equal(a, b), "view %%d differs in %%d words" %% (i, int((a != b).sum()))
 lit = lambda w: int(((w != 0x21212121) & (w != 0)).sum())

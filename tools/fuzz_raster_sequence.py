@@ -26,6 +26,7 @@ for seed in range(first, first + count):
     rng = np.random.RandomState((15485863 * seed + 11) % (1 << 32))
     W, H = int(rng.choice([120, 200, 257])), int(rng.choice([90, 131, 160]))
     outs = [DeviceArray((H, W), np.uint32, 0x5A) for _ in range(3)]
+    scratch = DeviceArray((H, W), np.uint32, 0x5A)
     k = 0
     mirt.set_frames_in_flight(1)
     in_flight = 1
@@ -38,7 +39,7 @@ for seed in range(first, first + count):
             mirt.scene_upload(scene)
         if rng.rand() < 0.15:
             mirt.sync()
-            in_flight = 3 - in_flight
+            in_flight = int(rng.choice([1, 2, 3, 4]))
             mirt.set_frames_in_flight(in_flight)
         nl = int(rng.randint(1, 3))
         L = np.zeros((nl, 7), np.float32)
@@ -63,6 +64,8 @@ for seed in range(first, first + count):
                 mirt.cull_device(v, flags)                  # ... so a frame drawn as two calls culls before each of them
                 mirt.rasterise_device(v, L, IND, ys, H, 0, outs[bi].ptr, W * 4)
             else:
+                if rng.rand() < 0.3:                        # a ray-traced frame takes the turn the cull step expected: the flags must follow the rasteriser
+                    mirt.raytrace_device(v, L, IND, mirt.RT_AUTO, 0, H, 0, scratch.ptr, W * 4)
                 mirt.rasterise_device(v, L, IND, 0, H, 0, outs[bi].ptr, W * 4)
             pending.append((bi, want, "step %d n %d flags %d in_flight %d banded %s" % (step, len(scene), flags, in_flight, banded)))
         mirt.sync()
@@ -72,7 +75,7 @@ for seed in range(first, first + count):
                 bad += 1
                 print("MISMATCH seed", seed, tag, "words", int((got != want).sum()), flush=True)
     mirt.set_frames_in_flight(1)
-    for b in outs:
+    for b in outs + [scratch]:
         b.free()
 print("fuzz: %d rasteriser call sequences from seed %d against the oracle, %d mismatching frames" % (count, first, bad))
 mirt.shutdown()

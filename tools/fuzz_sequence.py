@@ -21,7 +21,7 @@ for seed in range(first, first + count):
         print("... %d sequences, %d mismatching frames so far" % (seed - first + 1, bad), flush=True)
     rng = np.random.RandomState((104729 * seed + 7) % (1 << 32))
     W, H = int(rng.choice([160, 256, 333])), int(rng.choice([96, 144, 200]))
-    outs = [DeviceArray((H, W), np.uint32, 0x5A) for _ in range(3)]
+    outs = [DeviceArray((H, W), np.uint32, 0x5A) for _ in range(4)]
     ref = DeviceArray((H, W), np.uint32, 0x5A)
     scene, lights, view, aa, soft = None, None, None, 1, None
     pending = []                                            # (buffer index, expected image)
@@ -86,12 +86,12 @@ for seed in range(first, first + count):
             drain(); soft = None; mirt.set_soft_shadows(1)
         if rng.rand() < 0.1:
             drain()
-            in_flight = 3 - in_flight
+            in_flight = int(rng.choice([1, 2, 3, 4]))
             mirt.set_frames_in_flight(in_flight)
-        # a run of up to three frames with these settings (camera and/or first light moving from frame to frame): the expected
+        # a run of up to four frames with these settings (camera and/or first light moving from frame to frame): the expected
         # frames first (brute force, one at a time), then the binned frames queued back to back -- overlapping when two are in flight
         run = []
-        for j in range(int(rng.randint(1, 4))):
+        for j in range(int(rng.randint(1, 5))):
             if j and rng.rand() < 0.7:
                 view = new_view()
             if j and rng.rand() < 0.4:
@@ -104,7 +104,7 @@ for seed in range(first, first + count):
         for (v, L, sft, want) in run:
             if sft is not None:
                 mirt.sync(); mirt.set_soft_shadows(4, sft)
-            bi = k % 3; k += 1
+            bi = k % 4; k += 1
             if rng.rand() < 0.25:                           # the frame as two bands
                 ys = int(rng.randint(1, H - 1))
                 mirt.raytrace_device(v, L, IND, mode, 0, ys, 0, outs[bi].ptr, W * 4)

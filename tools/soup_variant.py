@@ -27,5 +27,6 @@ for lights, tag in ((LIGHT, "1 light"), (np.zeros((0, 7), np.float32), "no light
         if it >= 6:
             for k, v in st["kernel_ms"].items():
                 acc[k] = acc.get(k, 0.0) + v / 10
-    print("%-9s kernel_ms %s tests %d" % (tag, {k: round(v, 4) for k, v in acc.items() if v}, st["tests"]))
+    print("%-9s kernel_ms %s tests %d candidates %d steps p/s %d/%d drains %d" % (tag, {k: round(v, 4) for k, v in acc.items() if v}, st["tests"],
+          st["candidates"], st["steps_primary"], st["steps_shadow"], st["drains"]))
 mirt.shutdown()
