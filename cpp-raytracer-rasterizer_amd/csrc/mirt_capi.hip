@@ -47,6 +47,7 @@ struct RtTraceFrame {                            // (rt_trace.hip)
     const ShadeRow *shade;
     const uint32_t *light_off;
     const LightRow *light_rows;
+    const uint32_t *light_tri;
     const BinFrameDesc *light_frames;
     int tiles_x;
     int cube_bins;
@@ -61,7 +62,8 @@ struct RtTraceFrame {                            // (rt_trace.hip)
 template <bool AA> __global__ void k_rt_trace2(const RtTraceFrame);
 __global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *);
 __global__ void k_geo_table(const float *, int, GeoRow *, ShadeRow *);
-__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t);
+__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t,
+                                    const float *, const float *, uint32_t *);
 size_t rt_trace_lds_bytes(int waves);
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
 __global__ void k_cull(const float *, int, const CullParams, uint8_t *);
@@ -164,6 +166,7 @@ struct LightCache {
     uint32_t *d_off = nullptr;                   // nbins + 1
     uint32_t cap_bins = 0, nbins = 0;
     LightRow *d_rows = nullptr;                  // expanded candidates in key order
+    uint32_t *d_row_tri = nullptr;               // the triangle of each row
     uint32_t cap_rows = 0, nrows = 0;
     int shells = 1;                              // depth shells per bin of the tables held
     float *d_origins = nullptr;                  // (1 + MIRT_MAX_LIGHTS) x 3
@@ -653,12 +656,14 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
         if (npairs > C.cap_rows) {
             C.cap_rows = 0;
             if ((rc = dev_realloc(&C.d_rows, (size_t)npairs + npairs / 8 + 1024))) return rc;
+            if ((rc = dev_realloc(&C.d_row_tri, (size_t)npairs + npairs / 8 + 1024))) return rc;
             C.cap_rows = npairs + npairs / 8 + 1024;
         }
         C.nrows = npairs;
         if (npairs)
             hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((npairs + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.n, C.d_rows, (const uint32_t *)nullptr, 0u);
+                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.n, C.d_rows, (const uint32_t *)nullptr, 0u,
+                               g.d_tris, C.d_origins, C.d_row_tri);
         HIP_TRY(hipGetLastError());
         S.bin_key_valid = false;                             // the stream's pair list now holds the light pass
         S.last_bin_mode = -1;
@@ -809,7 +814,8 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         }
         const uint32_t expect = std::max<uint32_t>(S.bin_entries, 1u);
         hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                           S.d_bin_off + light_key0, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used);
+                           S.d_bin_off + light_key0, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used,
+                           g.d_tris, S.d_origins, (uint32_t *)nullptr);
     }
     // the order the trace kernel's waves take the tile pairs in: longest lists first
     const uint32_t npairs = (uint32_t)((bs.frame0.nbu + 1) / 2) * (uint32_t)(bs.frame0.j1 - bs.frame0.j0);
@@ -844,6 +850,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.shade = g.d_shade;
     tf.light_off = transient ? S.d_bin_off + light_key0 : g.lc.d_off;
     tf.light_rows = transient ? S.d_light_rows : g.lc.d_rows;
+    tf.light_tri = transient ? S.d_entries : g.lc.d_row_tri;
     tf.light_frames = transient ? S.d_frames + 1 : g.lc.d_frames;
     tf.tiles_x = bs.frame0.nbu;
     tf.cube_bins = cube_bins;
@@ -1246,7 +1253,7 @@ extern "C" void mirt_shutdown(void)
                          (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, (void *)S.d_tmp_vals, (void *)S.d_bucket })
             if (p) (void)hipFree(p);
     for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }
-    for (void *p : { (void *)g.d_geo, (void *)g.d_shade, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
+    for (void *p : { (void *)g.d_geo, (void *)g.d_shade, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_row_tri, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
         if (p) (void)hipFree(p);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos })
         if (p) (void)hipFree(p);

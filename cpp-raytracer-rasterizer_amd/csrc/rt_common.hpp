@@ -40,6 +40,17 @@ MIRT_HD float origin_near(v3 v0, v3 v1, v3 v2, v3 S)
     return (dc - R) - (0.0009765625f * (dc + R) + 1.0e-6f);
 }
 
+// The matching UPPER bound: no hit point the reference can compute on this triangle lies farther from S (same sphere, same
+// slack on the other side).  Lets a shadow ray that surely hits the triangle conclude "occluded" without the exact distance
+// (rt_trace.hip, sure_occluder).
+MIRT_HD float origin_far(v3 v0, v3 v1, v3 v2, v3 S)
+{
+    const v3 c = V3((v0.x + v1.x + v2.x) * (1.0f / 3.0f), (v0.y + v1.y + v2.y) * (1.0f / 3.0f), (v0.z + v1.z + v2.z) * (1.0f / 3.0f));
+    const float R = sqrtf(fmaxf(fmaxf(dot3(sub3(v0, c), sub3(v0, c)), dot3(sub3(v1, c), sub3(v1, c))), dot3(sub3(v2, c), sub3(v2, c))));
+    const float dc = sqrtf(dot3(sub3(c, S), sub3(c, S)));
+    return (dc + R) + (0.0009765625f * (dc + R) + 1.0e-6f);
+}
+
 MIRT_HD OriginRow make_origin_row(const float *t15, v3 S)
 {
     v3 v0 = ld3(t15), v1 = ld3(t15 + 3), v2 = ld3(t15 + 6);
@@ -93,6 +104,24 @@ __device__ __forceinline__ bool maybe_hit(const TestDots &d)
     const float b = __uint_as_float(__float_as_uint(d.qv) ^ sgn);
     const float slack = __builtin_fmaf(fabsf(d.den), 1.00000095367431640625f, -(a + b));
     return fminf(fminf(a, b), slack) >= -2.384185791015625e-07f;
+}
+
+// A test the reference is CERTAIN to accept (given the filter let it through): with s = sign(e1e2d), a = s*be2d, b = s*e1bd,
+// D = |e1e2d|:
+//   u = fl(a / D) >= 0 exactly when a >= 0 (a quotient of non-negative operands rounds to a non-negative value; -0 counts as
+//   >= 0 on both sides), likewise v and b, and t = fl(e1e2b / e1e2d) with s * e1e2b;
+//   fl(u + v) <= 1: u <= (a/D)(1 + 2^-24), v likewise, their rounded sum <= ((a + b)/D)(1 + 2^-24)^2, and fl(a + b) >=
+//   (a + b)(1 - 2^-24); so fl(a + b) < fl(D (1 - 2^-20)) gives (a + b)/D < 1 - 2^-21 and the sum stays below 1.  The strict
+//   `<` also excludes D == 0 (then a = b = 0 and u = 0/0 is NaN: rejected).  NaN operands fail the comparisons.
+// Used by shadow rays only: a certain hit whose every point is closer to the light than 0.99 r (origin_far) occludes -- any-hit is
+// exact (SURVEY A-5) -- without the divisions, the hit point or its distance ever being computed.
+__device__ __forceinline__ bool sure_hit(const TestDots &d, float e1e2b)
+{
+    const uint32_t sgn = __float_as_uint(d.den) & 0x80000000u;
+    const float a = __uint_as_float(__float_as_uint(d.pu) ^ sgn);
+    const float b = __uint_as_float(__float_as_uint(d.qv) ^ sgn);
+    const float tn = __uint_as_float(__float_as_uint(e1e2b) ^ sgn);          // s * e1e2b: t = tn / D
+    return fminf(a, b) >= 0.0f && (a + b) < fabsf(d.den) * 0.99999904632568359375f && tn >= 0.0f;
 }
 
 // ---- the same for two rays per lane (packed FP32, mirt_math2.hpp) ------------------------------------------

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tri
     shade[t] = sr;
 }
 
-// rows[p] = origin row of triangle entries[p] for the light its key belongs to, with the triangle index in r2.w: the sorted
-// pair list of the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.  bin_off points at the
+// rows[p] = origin row of triangle entries[p] for the light its key belongs to, with the `far` bound of that triangle from that
+// light in r2.w (origin_far: no point of it is farther), and row_tri[p] = the triangle (for the few pairs that reach the exact
+// stage): the sorted pair list of the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.  bin_off points at the
 // first light key (the pairs of keys in front of it -- a camera frame binned in the same pass -- are not light pairs);
 // bin_off[k * keys_per_light] is where the pairs of light k start (keys_per_light = 6 * B * B * depth shells).  pair_count /
 // pair_cap (nullable): the pass that sized its list from an earlier frame's count leaves its tables untouched when the list
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tri
 __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ entries,
                                                            int nlights, uint32_t keys_per_light,
                                                            const OriginRow *__restrict__ light_tab, int n,
-                                                           LightRow *__restrict__ rows, const uint32_t *__restrict__ pair_count, uint32_t pair_cap)
+                                                           LightRow *__restrict__ rows, const uint32_t *__restrict__ pair_count, uint32_t pair_cap,
+                                                           const float *__restrict__ tris15, const float *__restrict__ origins /* (1 + nlights) x 3 */,
+                                                           uint32_t *__restrict__ row_tri /* nullable: entries itself serves */)
 {
     if (pair_count && *pair_count > pair_cap) return;
     const uint32_t first = bin_off[0], total = bin_off[(size_t)nlights * keys_per_light];
@@ -75,8 +78,10 @@ __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__res
         while (k + 1 < nlights && bin_off[(size_t)(k + 1) * keys_per_light] <= p) k++;
         const uint32_t tri = entries[p];
         LightRow r = light_tab[(size_t)k * n + tri];
-        r.r2.w = __uint_as_float(tri);
+        const float *t15 = tris15 + (size_t)15 * tri;
+        r.r2.w = origin_far(ld3(t15), ld3(t15 + 3), ld3(t15 + 6), ld3(origins + 3 * (1 + k)));
         rows[p] = r;
+        if (row_tri) row_tri[p] = tri;
     }
 }
 
@@ -116,7 +121,8 @@ __device__ __forceinline__ void wave_lds_fence()
 // triangle float4); primary rays find it in the wave's LDS slice, staged with the candidate's origin row -- no memory round
 // trip inside the drain (their queue never outlives the staged chunk).
 template <bool SHADOW>
-__device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, const float4 *__restrict__ geo, v3 start)
+__device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, const float4 *__restrict__ geo, v3 start,
+                                         const uint32_t *__restrict__ row_tri = nullptr)
 {
     wave_lds_fence();
     if (lane < count) {
@@ -126,7 +132,8 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
         if (u + v <= 1.0f && u >= 0.0f && v >= 0.0f && t >= 0.0f) {                  // :239
             float4 g0, g1, g2;
             if (SHADOW) {
-                const float4 *g = geo + (size_t)a.y * 3;
+                const uint32_t tri = row_tri ? row_tri[a.y] : a.y;         // (a.y = the candidate's row; the origin tables' rows are the triangles)
+                const float4 *g = geo + (size_t)tri * 3;
                 g0 = g[0]; g1 = g[1]; g2 = g[2];
             } else {
                 const float4 *g = s.geo + (a.x >> 8) * 3;
@@ -154,9 +161,10 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
 
 // Drains TR_DRAIN pairs and moves the rest of the queue to its front.
 template <bool SHADOW>
-__device__ __forceinline__ void tr_drain_full(TrWaveLds &s, int lane, int &qn, const float4 *__restrict__ geo, v3 start)
+__device__ __forceinline__ void tr_drain_full(TrWaveLds &s, int lane, int &qn, const float4 *__restrict__ geo, v3 start,
+                                              const uint32_t *__restrict__ row_tri = nullptr)
 {
-    tr_drain<SHADOW>(s, lane, TR_DRAIN, geo, start);
+    tr_drain<SHADOW>(s, lane, TR_DRAIN, geo, start, row_tri);
     const int rest = qn - TR_DRAIN;
     float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint2 a = make_uint2(0u, 0u);
@@ -223,6 +231,7 @@ struct RtTraceFrame {
     const ShadeRow *shade;            // n shading rows (k_geo_table)
     const uint32_t *light_off;        // light-cube keys of all light positions: first row of each, nlights*6*B*B*light_shells + 1
     const LightRow *light_rows;       // expanded candidates ordered by light-cube key (k_expand_light_rows)
+    const uint32_t *light_tri;        // the triangle of each of them
     const BinFrameDesc *light_frames; // 6 per light position: the depth-shell parameters (the faces of a light share them)
     int tiles_x;                      // camera bins per row
     int cube_bins;                    // B: light-cube bins per face side
@@ -261,15 +270,21 @@ __global__ __launch_bounds__(256) void k_tile_order(const uint32_t *__restrict__
             cls = (int)min(max(r.nA, r.nB) / ORDER_CLASS_STEP, (uint32_t)(ORDER_CLASSES - 1));
         }
     }
-    // one atomic per (wave, class present): a class counter bumped once per record would serialise ~7 ns apiece
+    // ONE atomic instruction per wave: lane c adds the wave's count of class c (a class counter bumped once per record would
+    // serialise ~7 ns apiece; eight dependent atomics in a row made this kernel 13 us of round trips)
+    unsigned long long m[ORDER_CLASSES];
+    uint32_t mine = 0;
 #pragma unroll
     for (int c = 0; c < ORDER_CLASSES; c++) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
-        if (!m) continue;
-        uint32_t base = 0;
-        if (lane == __builtin_ctzll(m)) base = atomicAdd(&counters[16 + c], (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
-        if (cls == c) order[(size_t)c * npairs + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        m[c] = __builtin_amdgcn_ballot_w64(cls == c);
+        if (lane == c) mine = (uint32_t)__popcll(m[c]);
+    }
+    uint32_t base = 0;
+    if (lane < ORDER_CLASSES && mine) base = atomicAdd(&counters[16 + lane], mine);
+#pragma unroll
+    for (int c = 0; c < ORDER_CLASSES; c++) {
+        const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)base, c);
+        if (cls == c) order[(size_t)c * npairs + bc + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
     }
 }
 
@@ -506,64 +521,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                         }
                     }
                     ncand_l += (endA - eA) + (endB - eB);
-                    // the lane walks list A, then list B
+                    // the lane walks list A, then list B.  Per step: the filter; a candidate it lets through is either a CERTAIN
+                    // occluder (sure_hit, and the whole triangle closer to the light than 0.99 r: nothing left to compute, the ray
+                    // is done) or goes to the exact stage's queue.  The next row is requested once the step knows which it is.
+                    const uint32_t *row_tri = brute ? nullptr : tf.light_tri;
                     const bool firstA = eA < endA;
                     uint32_t e = firstA ? eA : eB, end = firstA ? endA : endB, pix = firstA ? (uint32_t)lane : (uint32_t)lane + 64u;
                     v3 crd = firstA ? half0(rd) : half1(rd);
                     float cthr = firstA ? thr.x : thr.y;
                     bool pend = firstA && eB < endB;
                     bool act = e < end;
+                    bool occA = false, occB = false;                 // certain occlusions found by the lane itself
                     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0;
                     if (act) { const float4 *src = rows4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
                     TM_SEG(6)
                     while (wballot(act)) {
                         nsteps_s++;
-                        // request the next row before this one is tested: the next of this list, or the first of list B
-                        const bool cont = act && (e + 1 < end);
-                        const bool sw = act && !cont && pend;
-                        const uint32_t ne = cont ? e + 1 : eB;
-                        const bool nact = cont || sw;
-                        float4 n0 = c0, n1 = c1, n2 = c2;
-                        if (nact) { const float4 *src = rows4 + (size_t)ne * 3; n0 = src[0]; n1 = src[1]; n2 = src[2]; }
                         const TestDots td = test_dots(c0, c1, c2, crd);          // negD = rDir (:310, :229)
                         // a candidate none of whose points is closer to the light than 0.99 r cannot occlude (:313)
                         const bool pass = act && !(c1.w > cthr) && maybe_hit(td);
+                        const bool sure = pass && !brute && c2.w < cthr && sure_hit(td, c0.w);
+                        const bool queue = pass && !sure;
                         ntests += (unsigned)__popcll(wballot(act));
-                        const unsigned long long m = wballot(pass);
-                        bool occ = false;
+                        const unsigned long long m = wballot(queue);
+                        bool occ = sure;
                         if (m) {
-                            if (pass) {
+                            if (queue) {
                                 const int at = qn + wave_rank(m);
                                 s.q[at] = make_float4(td.den, td.pu, td.qv, c0.w);
-                                s.qa[at] = make_uint2(pix, brute ? e : __float_as_uint(c2.w));     // the candidate's triangle
+                                s.qa[at] = make_uint2(pix, e);                   // the candidate's row
                             }
                             qn += __popcll(m);
                             if (qn >= TR_DRAIN) {
                                 TM_SEG(7)
-                                do { tr_drain_full<true>(s, lane, qn, geo4, L); ndrains++; } while (qn >= TR_DRAIN);
+                                do { tr_drain_full<true>(s, lane, qn, geo4, L, row_tri); ndrains++; } while (qn >= TR_DRAIN);
                                 TM_SEG(8)
-                                occ = act && !sw && s.flag[pix] != 0u;           // found occluded: the rest of this list is moot
+                                occ = occ || (act && s.flag[pix] != 0u);         // found occluded: the rest of this list is moot
                             }
                         }
+                        if (sure) { if (pix < 64u) occA = true; else occB = true; }
+                        // on: the next row of this list, or -- list done or ray occluded -- the first of list B
+                        const bool cont = act && !occ && e + 1 < end;
+                        const bool sw = act && !cont && pend;
                         if (sw) { crd = half1(rd); cthr = thr.y; pix = (uint32_t)lane + 64u; end = endB; pend = false; }
-                        e = ne; c0 = n0; c1 = n1; c2 = n2;
-                        act = nact;
-                        if (wballot(occ)) {
-                            if (occ) {
-                                act = pend;
-                                if (pend) {                                      // on to list B (its first row was not requested ahead)
-                                    crd = half1(rd); cthr = thr.y; pix = (uint32_t)lane + 64u; e = eB; end = endB; pend = false;
-                                    const float4 *src = rows4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2];
-                                }
-                            }
-                        }
+                        e = cont ? e + 1 : eB;
+                        act = cont || sw;
+                        if (act) { const float4 *src = rows4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
                     }
                     TM_SEG(7)
-                    if (qn) { tr_drain<true>(s, lane, qn, geo4, L); qn = 0; ndrains++; }
+                    if (qn) { tr_drain<true>(s, lane, qn, geo4, L, row_tri); qn = 0; ndrains++; }
                     TM_SEG(8)
                     // occluded (:313-314); any-hit is exact
-                    if (s.flag[lane] != 0u) { D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f; }
-                    if (s.flag[lane + 64] != 0u) { D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f; }
+                    if (occA || s.flag[lane] != 0u) { D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f; }
+                    if (occB || s.flag[lane + 64] != 0u) { D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f; }
                     result = add3p(result, D);                     // (:319)
                     if ((k + 1) % f.samples == 0) result2 = add3p(result2, result);   // (:322) after each light's samples
                 }

@@ -1037,10 +1037,10 @@ from devbuf import DeviceArray
 mirt.init(0)
 L = np.zeros((0, 7), np.float32)                   # no light: camera-only binning passes, nothing else sizes the pair list
 W, H = 320, 200
-tris = mirt.scene_soup(8, 4000, 0.06)
+tris = mirt.scene_soup(8, 20000, 0.3)           # large triangles: one tile each from afar, dozens of tiles each from close by
 mirt.scene_upload(tris)
 far = [mirt.make_view((0.001 * i, 0, -40.0), mirt.rot_from_yaw(0.0, 1.0), 100.0, W, H) for i in range(6)]
-near = mirt.make_view((0.02, 0, -1.6), mirt.rot_from_yaw(0.01, 1.0), 1000.0, W, H)     # zoomed in: every triangle covers dozens of tiles
+near = mirt.make_view((0.02, 0, -2.4), mirt.rot_from_yaw(0.01, 1.0), 100.0, W, H)
 def frame(v, mode):
     b = DeviceArray((H, W), np.uint32, 0x21)
     mirt.raytrace_device(v, L, (0.2, 0.2, 0.2), mode, 0, H, 0, b.ptr, W * 4)
