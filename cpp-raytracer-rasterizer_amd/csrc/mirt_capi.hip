@@ -200,6 +200,8 @@ struct Ctx {
     int culled_latest = 0;                       // which copy the most recent cull call wrote (mirt_scene_get_culled reads it)
     uint64_t culled_ver[MAX_FLIGHT] = {};        // what each copy holds: the number of the cull call (or upload) it comes from
     uint64_t cull_calls = 0;
+    hipEvent_t ev_cull_read[MAX_FLIGHT] = {};    // per stream: its last copy OUT of another stream's flags has been made ...
+    int cull_read_src[MAX_FLIGHT] = { -1, -1, -1, -1 };   // ... of this copy (-1: none pending); the next cull step into it waits
     RtScratch rt[MAX_FLIGHT];                    // per-stream tables of the non-tile ray-trace paths (frames in flight)
     GeoRow *d_geo = nullptr;                     // n geometry rows (built by mirt_scene_upload)
     ShadeRow *d_shade = nullptr;                 // n shading rows (likewise)
@@ -1223,6 +1225,8 @@ extern "C" int mirt_init(int device)
     for (int i = 0; i < MAX_FLIGHT; i++) {
         HIP_TRY(hipStreamCreateWithFlags(&g.streams[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_order[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_cull_read[i], hipEventDisableTiming));
+        g.cull_read_src[i] = -1;
     }
     g.stream = g.streams[0];
     g.in_flight = 1;
@@ -1271,6 +1275,7 @@ extern "C" void mirt_shutdown(void)
     for (RasterScratch &R : g.raster) raster_scratch_free(R);
     for (int si = 0; si < MAX_FLIGHT; si++) for (int i = 0; i < EV_COUNT; i++) if (g.ev_sets[si][i]) { (void)hipEventDestroy(g.ev_sets[si][i]); g.ev_sets[si][i] = nullptr; }
     for (hipEvent_t e : g.ev_order) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_cull_read) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < MAX_FLIGHT; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
     g = Ctx();
 }
@@ -1441,6 +1446,11 @@ extern "C" int mirt_cull_device(const mirt_view *view, int flags)
     const int half = next_si();
     hipStream_t st = g.streams[half];
     (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (see call_begin)
+    for (int r = 0; r < MAX_FLIGHT; r++)         // a frame of another stream may still be copying this copy's previous flags
+        if (g.cull_read_src[r] == half && r != half) {
+            HIP_TRY(hipStreamWaitEvent(st, g.ev_cull_read[r], 0));
+            g.cull_read_src[r] = -1;
+        }
     hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.d_tris, g.n, cp, g.d_culled + (size_t)half * g.n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g.ev_order[half], st));
@@ -1623,6 +1633,8 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
         HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_order[from], 0));
         HIP_TRY(hipMemcpyAsync(g.d_culled + (size_t)g.si * g.n, g.d_culled + (size_t)from * g.n, (size_t)g.n, hipMemcpyDeviceToDevice, g.stream));
         g.culled_ver[g.si] = g.culled_ver[from];
+        HIP_TRY(hipEventRecord(g.ev_cull_read[g.si], g.stream));       // (a later cull step into copy `from` must not overtake this read)
+        g.cull_read_src[g.si] = from;
     }
     g.pending_is_rt = false;
     if (y1 == y0) { call_end(); return MIRT_OK; }

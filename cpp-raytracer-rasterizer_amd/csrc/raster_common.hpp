@@ -34,6 +34,17 @@ struct Span {
 };
 static_assert(sizeof(Span) == 48, "span record must be 48 bytes");
 
+// A span as the small-scene kernel (k_raster_small) keeps it in LDS: the depth-test and shading constants of one (triangle, row).
+constexpr int SMALL_MAX_TRIS = 64;
+struct SmallSpan {
+    int ax, dx;                                     // Span::ax, Span::dx
+    float azinv, zstep;
+    float ap[3], pstep[3];
+    float nrm[3], col[3];                           // triangles[tri].normal (NOT normalised by the rasteriser, :578) and .color
+    int tri, pad[3];
+};
+static_assert(sizeof(SmallSpan) == 80, "row-list record must be 80 bytes (16-byte aligned)");
+
 struct RasterScratch {
     TriSetup *setup = nullptr;       // n
     uint32_t *row_base = nullptr;    // n + 1 (exclusive scan of TriSetup::rows), then block sums

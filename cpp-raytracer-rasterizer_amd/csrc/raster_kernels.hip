@@ -18,6 +18,7 @@
 //   k_raster_resolve  one thread per pixel: decode the winner, rebuild its pos3d, PixelShader, and write the
 //                     XRGB word (+ optional float colour / depth / index planes) with coalesced stores
 #include "raster_common.hpp"
+#include "mirt_math2.hpp"
 #include "scan.hpp"
 
 #include <limits.h>
@@ -444,6 +445,151 @@ __global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
     f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = interior ? pack_xrgb(colour) : 0u;
 }
 
+// ---- scenes of at most 64 triangles: depth test in registers, no key buffer ---------------------------------------------------
+// The reference's own scene has 30 triangles, 20 of them visible.  For it the atomic z-buffer is the wrong tool: k_raster_frag
+// moves 8 bytes per fragment through the memory-side atomic units (~1.3 TB/s chip-wide: 45 us at 4K) and k_raster_resolve reads
+// the keys back and re-zeroes them.  With so few triangles a row holds a handful of spans, so here a workgroup takes 512
+// pixels of one row: its first wave collects the spans of that row that reach into those pixels (span constants, plus the
+// triangle's normal and colour) into LDS, in triangle order; every thread then owns TWO pixels (x and x + 256), evaluates
+//     zinv = a.zinv + zstep * float(x - a.x - 1)                                   (rasteriser.cpp:667)
+// for the listed spans that contain each of them, keeps the largest (strict `>` in ascending triangle order = the reference's
+// sequential `zinv > depthBuffer[y][x]`, :606: largest zinv, lowest index among exact ties) and shades the winner -- PixelShader
+// (:549-589) for both pixels in packed FP32, every operand from LDS.  Same arithmetic on the same operands as k_raster_frag +
+// k_raster_resolve, so depthBuffer, pixelColours and the surface come out bit-identical; the frame writes 4 bytes per pixel
+// and reads nothing but the spans.
+constexpr int SMALL_PX = 512;                       // pixels of a row per wave: four passes of 128 (two per lane)
+constexpr int SMALL_ROWS = 4;                       // rows per workgroup = waves per workgroup: every wave works alone on its row
+
+__global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
+{
+    __shared__ __attribute__((aligned(16))) SmallSpan s_list[SMALL_ROWS][SMALL_MAX_TRIS];
+    const int xbase = (int)blockIdx.x * SMALL_PX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rr = wave, y = f.y0 + (int)blockIdx.y * SMALL_ROWS + wave;       // this wave's row; no wave waits for another
+    if (y >= f.y1) return;
+    int count;
+    {
+        // the spans of row y that draw into [xbase, xbase + SMALL_PX): one lane per triangle, kept in triangle order, as five
+        // 16-byte words each (span constants + the triangle's normal and colour)
+        bool take = false;
+        float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0, v2 = v0, v3 = v0, v4 = v0;
+        if (lane < f.n) {
+            const TriSetup &st = f.scratch.setup[lane];
+            const int r0 = st.r0, rows = st.rows;
+            const size_t base = f.scratch.row_base[lane];
+            if (rows > 0 && y >= r0 && y < r0 + rows && base + (size_t)rows <= f.scratch.cap_rows) {
+                const float4 *src = reinterpret_cast<const float4 *>(f.scratch.spans + base + (uint32_t)(y - r0));
+                const float4 a = src[0], b = src[1], c = src[2];      // {ax, dx, azinv, zstep | ap.xyz, pstep.x | pstep.yz, tri, y}
+                const float *t15 = f.tris15 + (size_t)15 * lane;
+                const int ax = __float_as_int(a.x), dx = __float_as_int(a.y);
+                // fragments are x = ax+1 .. ax+dx; those outside [0, W) are never produced (:663, E-2)
+                const long long lo = std::max<long long>((long long)ax + 1, (long long)xbase);
+                const long long hi = std::min<long long>((long long)ax + dx, (long long)std::min(f.W, xbase + SMALL_PX) - 1);
+                take = dx > 0 && lo <= hi;
+                v0 = a; v1 = b;
+                v2 = make_float4(c.x, c.y, t15[9], t15[10]);          // pstep.yz, normal.xy
+                v3 = make_float4(t15[11], t15[12], t15[13], t15[14]);    // normal.z, colour
+                v4 = make_float4(__int_as_float(lane), 0.0f, 0.0f, 0.0f);
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+        if (take) {
+            float4 *dst = reinterpret_cast<float4 *>(&s_list[rr][__popcll(m & ((1ull << lane) - 1ull))]);
+            dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4;
+        }
+        count = __popcll(m);
+        // (wave-private LDS: the wave's own accesses execute in order; this only stops the compiler from moving them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const v3p camp = splat3(ld3(f.cam));
+    for (int seg = 0; seg < SMALL_PX / 128; seg++) {
+        // the lane's two pixels are neighbours: both inside or both outside a surface almost always, so a pass whose pixels
+        // nothing covers skips the shading whole, and the pair leaves as one 8-byte store
+        const int x0 = xbase + seg * 128 + 2 * lane, x1 = x0 + 1;
+        if (xbase + seg * 128 >= f.W) break;
+        const bool ok0 = x0 < f.W, ok1 = x1 < f.W;
+        // ---- depth test (:603-608) for both pixels against the row's spans, branch-free: the u64 key zinv_bits << 32 |
+        // (~triangle << 6 | list slot) of every span that draws the pixel with zinv > 0 (depthBuffer starts at 0, Update() :188),
+        // maximum kept = largest zinv, lowest triangle among exact ties -- the reference's strict `>` in triangle order ----
+        unsigned long long k0 = 0ull, k1 = 0ull;
+        const int seg_lo = xbase + seg * 128, seg_hi = seg_lo + 127;
+        for (int j = 0; j < count; j++) {
+            const SmallSpan &sp = s_list[rr][j];
+            // (wave-uniform: a span that draws none of this pass's 128 pixels is skipped whole)
+            if (__builtin_amdgcn_readfirstlane(sp.ax) >= seg_hi || (long long)__builtin_amdgcn_readfirstlane(sp.ax) + __builtin_amdgcn_readfirstlane(sp.dx) < seg_lo) continue;
+            const int i0 = x0 - sp.ax - 1, i1 = x1 - sp.ax - 1;                   // Bresenham's i of this pixel (:657)
+            const f2 z = splat2(sp.azinv) + splat2(sp.zstep) * (f2){ (float)i0, (float)i1 };   // :667
+            const uint32_t low = ((0x03FFFFFFu - (uint32_t)sp.tri) << 6) | (uint32_t)j;
+            const bool in0 = ok0 && (unsigned)i0 < (unsigned)sp.dx && z.x > 0.0f, in1 = ok1 && (unsigned)i1 < (unsigned)sp.dx && z.y > 0.0f;
+            const unsigned long long c0 = in0 ? ((unsigned long long)__float_as_uint(z.x) << 32) | low : 0ull;
+            const unsigned long long c1 = in1 ? ((unsigned long long)__float_as_uint(z.y) << 32) | low : 0ull;
+            k0 = c0 > k0 ? c0 : k0;
+            k1 = c1 > k1 ? c1 : k1;
+        }
+        const uint32_t bz0 = (uint32_t)(k0 >> 32), bz1 = (uint32_t)(k1 >> 32);
+        const int bj0 = k0 ? (int)(k0 & 63ull) : -1, bj1 = k1 ? (int)(k1 & 63ull) : -1;
+        const int bt0 = bj0 >= 0 ? s_list[rr][bj0].tri : -1, bt1 = bj1 >= 0 ? s_list[rr][bj1].tri : -1;
+
+        // ---- PixelShader (:549-589) of the two winners, packed ----
+        v3p colour = splat3(V3(0.0f, 0.0f, 0.0f));  // Update() cleared pixelColours (:189)
+        f2 fdist = splat2(0.0f);
+#ifdef MIRT_SMALL_NOSHADE
+        if (false) {
+#else
+        if (bj0 >= 0 || bj1 >= 0) {
+#endif
+            const SmallSpan &a = s_list[rr][bj0 >= 0 ? bj0 : 0], &b = s_list[rr][bj1 >= 0 ? bj1 : 0];
+            const f2 zinv = { __uint_as_float(bz0), __uint_as_float(bz1) };
+            const f2 fi = { (float)(x0 - a.ax - 1), (float)(x1 - b.ax - 1) };
+            const v3p ap = join3(ld3(a.ap), ld3(b.ap)), ps = join3(ld3(a.pstep), ld3(b.pstep));
+            const v3p p3 = add3p(ap, scale3p(ps, fi));                              // a.pos3d + pos3d*float(i) (:668)
+            const v3p normal = join3(ld3(a.nrm), ld3(b.nrm)), color = join3(ld3(a.col), ld3(b.col));
+            v3p P = V3P(div2(p3.x, zinv), div2(p3.y, zinv), div2(p3.z, zinv));      // pPos3d /= p.zinv (:557)
+            const float *m = f.invrot;                                              // * glm::inverse(cameraRot) (:559): vec * mat
+            P = V3P(m[0] * P.x + m[1] * P.y + m[2] * P.z, m[3] * P.x + m[4] * P.y + m[5] * P.z, m[6] * P.x + m[7] * P.y + m[8] * P.z);
+            P = add3p(P, camp);                                                     // += cameraPos (:560)
+            if (f.fd) fdist = distance3p(P, camp) - splat2(f.focal_plane);          // focalDistances (:563-565)
+            v3p result = splat3(V3(0.0f, 0.0f, 0.0f));
+            for (int k = 0; k < f.nlights; k++) {
+                const v3p L = splat3(ld3(f.lpos[k]));
+                const f2 r = distance3p(P, L);                                      // :574
+                const f2 A = { sphere_area(r.x), sphere_area(r.y) };                // :575
+                const v3p rDir = normalize3p(sub3p(L, P));                          // :577
+                const v3 lc = ld3(f.lcol[k]);
+                const v3p B = V3P(div2(splat2(lc.x), A), div2(splat2(lc.y), A), div2(splat2(lc.z), A));   // :579
+                const f2 d = dot3p(rDir, normal);                                   // normal NOT re-normalised here (:578)
+                const f2 mx = { (d.x < 0.0f) ? 0.0f : d.x, (d.y < 0.0f) ? 0.0f : d.y };   // std::max (:581)
+                result = add3p(result, scale3p(B, mx));
+            }
+            // currentReflectance(1,1,1) * (result + indirectLightPowerPerArea) * color (:587)
+            const v3p lit = mul3p(mul3p(splat3(V3(1.0f, 1.0f, 1.0f)), add3p(result, splat3(ld3(f.indirect)))), color);
+            colour = join3(bj0 >= 0 ? half0(lit) : V3(0.0f, 0.0f, 0.0f), bj1 >= 0 ? half1(lit) : V3(0.0f, 0.0f, 0.0f));
+            if (bj0 < 0) fdist.x = 0.0f;
+            if (bj1 < 0) fdist.y = 0.0f;
+        }
+        uint32_t word[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int x = h ? x1 : x0;
+            const v3 c = h ? half1(colour) : half0(colour);
+            // Update() paints every pixel black (:190); CalculateDOF then draws the interior only (:491-493)
+            const bool interior = x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1;
+            word[h] = interior ? pack_xrgb(c) : 0u;
+            if (!(h ? ok1 : ok0)) continue;
+            const size_t px = (size_t)y * f.W + x;
+            if (f.rgb) st3(f.rgb + 3 * px, c);
+            if (f.zinv) f.zinv[px] = __uint_as_float(h ? bz1 : bz0);
+            if (f.fd) f.fd[px] = h ? fdist.y : fdist.x;
+            if (f.index) f.index[px] = h ? bt1 : bt0;
+        }
+        uint32_t *dst = f.xrgb + (size_t)(y - f.row_origin) * f.pitch_words + x0;
+        if (ok1 && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0) *reinterpret_cast<uint2 *>(dst) = make_uint2(word[0], word[1]);
+        else { if (ok0) dst[0] = word[0]; if (ok1) dst[1] = word[1]; }
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------
 
 void raster_scratch_free(RasterScratch &s)
@@ -511,8 +657,11 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
 
     // The depth keys of the band must be zero (depthBuffer cleared by Update(), :188).  k_raster_resolve zeroes every key it
     // consumes, so after a completed frame the first `keys_zero_px` slots are zero again and only a larger band needs a memset.
+    // (Scenes of at most 64 triangles never touch the keys: k_raster_small below.)
+    static const bool small_off = [] { const char *e = getenv("MIRT_RASTER_SMALL"); return e && atoi(e) == 0; }();   // (A/B runs, tests of the atomic path)
+    const bool small = f.n <= SMALL_MAX_TRIS && !small_off;
     const size_t band_px = (size_t)f.W * band_rows;
-    if (band_px > s.keys_zero_px) {
+    if (!small && band_px > s.keys_zero_px) {
         begin(MIRT_K_CLEAR);
         s.keys_zero_px = 0;
         if (hipMemsetAsync(s.keys, 0, band_px * sizeof(unsigned long long), stream) != hipSuccess) return MIRT_ERR_HIP;
@@ -520,8 +669,9 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
         end(MIRT_K_CLEAR);
     }
 
+    auto set_scratch = [&]() { f.scratch = s; };
     begin(MIRT_K_RASTER_SETUP);
-    f.scratch = s;
+    set_scratch();
     if (f.n <= 4096) {
         hipLaunchKernelGGL(k_raster_vertex_scan, dim3(1), dim3(256), 0, stream, f);
     } else {
@@ -548,7 +698,7 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
         lds_rows = std::min(band_rows, lds_rows_max);
         tall = band_rows > lds_rows;
         if (tall && ensure_rows(s, worst_rows)) return MIRT_ERR_OUT_OF_MEMORY;      // slot table of the chunked kernel
-        f.scratch = s;
+        set_scratch();
         f.scratch.cap_rows = s.cap_spans;
     } else {
         const uint64_t key = frame_key(f, scene_version);
@@ -561,7 +711,7 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
             s.sizing_key = key;
             s.sizing_valid = true;
         }
-        f.scratch = s;
+        set_scratch();
         lds_rows = (int)std::min<uint32_t>(s.max_rows, (uint32_t)lds_rows_max);
         tall = s.max_rows > (uint32_t)lds_rows;
     }
@@ -579,6 +729,15 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     }
     if (tall) hipLaunchKernelGGL(k_raster_edges, dim3(f.n), dim3(256), 0, stream, f, lds_rows);
     end(MIRT_K_RASTER_SETUP);
+
+    // Scenes of at most 64 triangles: one kernel does the depth test in registers and shades (no key buffer, no atomics).
+    if (small) {
+        begin(MIRT_K_RASTER_RESOLVE);
+        hipLaunchKernelGGL(k_raster_small, dim3((f.W + SMALL_PX - 1) / SMALL_PX, (band_rows + SMALL_ROWS - 1) / SMALL_ROWS), dim3(256), 0, stream, f);
+        end(MIRT_K_RASTER_RESOLVE);
+        if (hipGetLastError() != hipSuccess) return MIRT_ERR_HIP;
+        return MIRT_OK;
+    }
 
     begin(MIRT_K_RASTER_FRAG);
     const int frag_blocks = (int)min((size_t)8192, (f.scratch.cap_rows + 3) / 4);

@@ -73,7 +73,9 @@ for seed in range(first, first + count):
             got = outs[bi].read()
             if not np.array_equal(got, want):
                 bad += 1
-                print("MISMATCH seed", seed, tag, "words", int((got != want).sum()), flush=True)
+                ys, xs = np.nonzero(got != want)
+                print("MISMATCH seed", seed, tag, "words", int((got != want).sum()), "first at (x, y, got, want):",
+                      [(int(x), int(y), hex(int(got[y, x])), hex(int(want[y, x]))) for y, x in list(zip(ys, xs))[:6]], flush=True)
     mirt.set_frames_in_flight(1)
     for b in outs + [scratch]:
         b.free()
