@@ -43,9 +43,12 @@ INDIRECT = (0.2, 0.2, 0.2)                                                    # 
 
 FLOP_PER_TEST = 60.0          # 57 add/mul + 3 div as written in raytracer.cpp:216-239
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: vector FP32 peak (counts FMA as 2; this path may not fuse)
+# what bit-exact parity leaves reachable: no FMA contraction (half the flops per instruction); packed v_pk_* where two rays share
+# a lane (78.6), one flop per lane and instruction otherwise (39.3)
+PEAK_REACHABLE_TFLOPS = {"no_fma_packed": 78.6, "no_fma_scalar": 39.3}
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 ISSUE_CEILING = 0.24          # measured VALU issue ceiling, wave-instr / clk / SIMD (profiles/r01_ubench_valu_lds.txt)
-ROUND = "r02"                 # which committed profiles/ files `traffic` and `valu_issue` are read from
+ROUND = "r03"                 # which committed profiles/ files `traffic` and `valu_issue` are read from
 ORBIT_STEP = 1.0e-3           # yaw per frame of the moving camera (rad)
 ORBIT_VIEWS = 64              # distinct views cycled through (consecutive frames never share one)
 
@@ -61,16 +64,42 @@ WORKLOADS = {
     "soup1m8k": ("rt", ("soup", 2, 1000000, 0.02), 7680, 4320, (0, 0, -2), 2160.0, 1.0),
     "raster4k": ("raster", ("cornell",), 3840, 2160, (0, 0, -3), 2160.0, 1.01),
 }
-SUB_RESULTS = ("soup100k", "raster4k", "soup1m8k")        # embedded in the default line
+DEFAULT_WORKLOAD = "soup100k"                              # the north star's target configuration (BASELINE configs[2]: 1080p, 100 k triangles)
+SUB_RESULTS = ("cornell1080", "raster4k", "soup1m8k")     # embedded in the default line
 SUB_RESULTS_SHARDED = ("soup1m8k",)                       # ... of a --gpus N > 1 run: BASELINE configs[4], the config the band split is for
 
 
+def csrc_digest():
+    """sha256 (first 16 hex digits) over the kernel sources: what a committed PMC summary must have been profiled at."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cpp-raytracer-rasterizer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+_stale_warned = set()
+
+
 def committed_profile(name):
+    """A committed PMC summary -- or None, with a warning, when it was profiled at other kernel sources than the ones running
+    (tools/store_profiles.py stamps `csrc_sha16`): a counter read from a file must not outlive the kernel it counted."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f)
+            doc = json.load(f)
     except (OSError, ValueError):
         return None
+    if doc.get("csrc_sha16") != csrc_digest():
+        if name not in _stale_warned:
+            _stale_warned.add(name)
+            print("bench.py: profiles/%s was collected at kernel sources %s, running %s: its counters are reported as null "
+                  "(re-run tools/collect_profiles.sh)" % (name, doc.get("csrc_sha16"), csrc_digest()), file=sys.stderr, flush=True)
+        return None
+    return doc
 
 
 def measured_traffic(workload, kernel_prefixes):
@@ -519,13 +548,17 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
             })
             kt = kernel_ms.get("trace", 0.0)
             kname = {mirt.RT_BRUTE: ("k_rt_tile<" if aa > 1 else "k_rt_tile2") if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
-                     mirt.RT_BINNED: "k_rt_trace"}[st["mode_used"]]
+                     mirt.RT_BINNED: "k_rt_trace2"}[st["mode_used"]]
             # algorithmic flops per launch = ray-triangle tests the launch executed x 60 flop per test as written in the
             # reference (brute force: rays x triangles; tile / binned kernels: filter evaluations counted in-kernel)
             tests_rank = float(st["tests"])
             ach = tests_rank * FLOP_PER_TEST / (kt * 1e-3) / 1e12 if kt > 0 else None
             out["roofline"] = {"bound": "valu", "kernel": kname, "achieved": None if ach is None else round(ach, 3),
                                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None if ach is None else round(ach / PEAK_FP32_TFLOPS, 4),
+                               "peak_reachable": PEAK_REACHABLE_TFLOPS,
+                               "frac_of_reachable": None if ach is None else round(ach / PEAK_REACHABLE_TFLOPS["no_fma_packed"], 4),
+                               "primary_fraction": "valu_issue (the kernel skips most of the reference's tests, so executed-test flops "
+                                                   "understate what the vector pipes do; issue slots do not)",
                                "traffic": measured_traffic(name, [kname]) if world == 1 else None,
                                "traffic_source": "profiles/%s_hbm_traffic.json (rocprofv3 PMC, bytes per launch)" % ROUND,
                                "tests_per_launch": int(tests_rank), "candidates_per_launch": int(st["candidates"]), "kernel_ms": round(kt, 5),
@@ -533,10 +566,10 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                "reference_tests_per_launch": int(rays_rank * len(tris)),
                                "reference_equivalent_tflops": None if kt <= 0 else round(rays_rank * len(tris) * FLOP_PER_TEST / (kt * 1e-3) / 1e12, 3),
                                "note": "FP32 VALU-bound: not a contraction, so no MFMA; peak counts an FMA as 2 flop but bit-exact "
-                                       "parity forbids FMA contraction, so the reachable ceiling is 1/2 of peak. achieved = filter tests the "
-                                       "launch EXECUTED x 60 flop (candidates skipped by binning, depth order or the near bound do not "
-                                       "count); reference_equivalent = the brute-force work of the reference (rays x triangles x 60) "
-                                       "over the same time"}
+                                       "parity forbids FMA contraction (peak_reachable). achieved = filter tests the launch EXECUTED x 60 "
+                                       "flop (candidates skipped by binning, depth order, the near bound, or settled as certain occluders "
+                                       "do not count: the better the skipping, the lower this fraction); reference_equivalent = the "
+                                       "brute-force work of the reference (rays x triangles x 60) over the same time"}
             # launches of consecutive frames overlap, so a launch's own duration understates what the chip does: the same work over
             # the FRAME time, and the launch alone on the device, beside it
             fach = tests_rank * FLOP_PER_TEST / (ms_frame * 1e-3) / 1e12
@@ -711,10 +744,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-results", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches its own ranks: one process per GPU under torch.distributed.run, started HERE, before
+        # this process has touched torch or the GPU (a process that has initialised HIP must never be replaced or forked from);
+        # the parent only waits and hands on the exit code -- non-zero if any rank died.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     env = Env(args)
     steps = args.steps if args.steps is not None else 20
     warmup = args.warmup if args.warmup is not None else 3
-    name = args.workload or "cornell1080"
+    name = args.workload or DEFAULT_WORKLOAD
     target = 0.1 if args.mode != "brute" else 0.0
     out = run_workload(env, name, steps, warmup, args.mode, not args.static_camera, not args.no_cpu_baseline, target_s=target)
     if args.workload is None and not args.no_sub_results:

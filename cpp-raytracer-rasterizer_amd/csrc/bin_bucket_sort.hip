@@ -162,11 +162,10 @@ __global__ __launch_bounds__(256) void k_bs_local(const uint32_t *__restrict__ k
 // bins per bucket = 1 << shift: 256 (measured on the 0.5 M pairs of the 100 k soup's camera frame: scatter + local take 57 /
 // 38 / 28 / 25 us at 32 / 64 / 128 / 256 bins per bucket -- fewer buckets mean longer contiguous runs in the scatter's
 // output), more where that many buckets would not fit the LDS counters (8192); more than 8192 buckets of 1024 bins is beyond
-// this sort.  MIRT_BS_SHIFT overrides the minimum.
+// this sort.
 int bucket_sort_shift(uint32_t nbins)
 {
-    static const int min_shift = [] { const char *e = getenv("MIRT_BS_SHIFT"); int v = e ? atoi(e) : 0; return (v >= 4 && v <= 10) ? v : 8; }();
-    int shift = min_shift;
+    int shift = 8;
     while (shift < 10 && ((nbins + 1u + (1u << shift) - 1u) >> shift) > 8192u) shift++;
     // few bins (the 64 x 64 light cube of a moving light: 24 576): smaller buckets, so that k_bs_local has a workgroup per CU
     // and no bucket holds tens of thousands of pairs (one workgroup places a bucket's pairs: 63 -> 20 us on the 100 k soup)

@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -32,22 +33,59 @@ void band_of(int rank, int world, int height, int *y0, int *y1)
     *y1 = *y0 + base + (rank < rem ? 1 : 0);
 }
 
-int band_gather_plan(int world, int root, int width, int height, int nviews, BandPiece *out, int max_pieces)
+int part_segments(int rank, int world, int height, int strip_rows)
+{
+    if (strip_rows <= 0) { int a, b; band_of(rank, world, height, &a, &b); return b > a ? 1 : 0; }
+    const int strips = (height + strip_rows - 1) / strip_rows;
+    return strips > rank ? (strips - rank + world - 1) / world : 0;
+}
+
+void part_segment(int rank, int world, int height, int strip_rows, int k, int *y0, int *y1)
+{
+    if (strip_rows <= 0) { band_of(rank, world, height, y0, y1); return; }
+    const long long s = (long long)rank + (long long)k * world;       // the k-th strip of this rank
+    *y0 = (int)std::min<long long>(s * strip_rows, height);
+    *y1 = (int)std::min<long long>((s + 1) * strip_rows, height);
+}
+
+int part_rows(int rank, int world, int height, int strip_rows)
+{
+    int rows = 0;
+    for (int k = 0, n = part_segments(rank, world, height, strip_rows); k < n; k++) {
+        int a, b;
+        part_segment(rank, world, height, strip_rows, k, &a, &b);
+        rows += b - a;
+    }
+    return rows;
+}
+
+int part_gather_plan(int world, int root, int width, int height, int nviews, int strip_rows, BandPiece *out, int max_pieces)
 {
     const size_t row = (size_t)width * 4, frame = (size_t)height * row;
     int n = 0;
     for (int r = 0; r < world; r++) {
         if (r == root) continue;
-        int a, b;
-        band_of(r, world, height, &a, &b);
-        if (b <= a) continue;
-        const size_t band = (size_t)(b - a) * row;
+        const int segs = part_segments(r, world, height, strip_rows);
+        const size_t mine = (size_t)part_rows(r, world, height, strip_rows) * row;      // this rank's rows of ONE view in its band buffer
         for (int v = 0; v < nviews; v++) {
-            if (n < max_pieces) out[n] = { (size_t)v * frame + (size_t)a * row, (size_t)v * band, band, r };
-            n++;
+            size_t before = 0;
+            for (int k = 0; k < segs; k++) {
+                int a, b;
+                part_segment(r, world, height, strip_rows, k, &a, &b);
+                const size_t bytes = (size_t)(b - a) * row;
+                if (bytes == 0) continue;
+                if (n < max_pieces) out[n] = { (size_t)v * frame + (size_t)a * row, (size_t)v * mine + before, bytes, r };
+                n++;
+                before += bytes;
+            }
         }
     }
     return n;
+}
+
+int band_gather_plan(int world, int root, int width, int height, int nviews, BandPiece *out, int max_pieces)
+{
+    return part_gather_plan(world, root, width, height, nviews, 0, out, max_pieces);
 }
 
 namespace {

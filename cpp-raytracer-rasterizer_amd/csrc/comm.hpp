@@ -11,6 +11,17 @@ constexpr int COMM_ID_BYTES = 128;      // == NCCL_UNIQUE_ID_BYTES
 // rows [y0, y1) of `rank` when `height` rows are split into `world` contiguous bands (sizes differ by at most one row)
 void band_of(int rank, int world, int height, int *y0, int *y1);
 
+// The rows of a rank as SEGMENTS of the frame, for either partition:
+//   strip_rows == 0   one contiguous band per rank (band_of): one binning pass and one launch chain per rank and frame -- what the
+//                     binned ray tracer wants, its per-frame cost having a part that does not shrink with the rows rendered;
+//   strip_rows  > 0   interleaved strips of that many rows, strip s to rank s % world -- every rank samples the whole height of the
+//                     frame, which evens out scenes whose cost is concentrated in some rows (the reference's schedule(auto) over
+//                     rows, raytracer.cpp:557, at the granularity a GPU launch needs).
+// A rank's band buffer holds its segments of one view back to back, views one after the other.
+int part_segments(int rank, int world, int height, int strip_rows);                          // how many segments the rank has
+void part_segment(int rank, int world, int height, int strip_rows, int k, int *y0, int *y1);  // its k-th: rows [y0, y1)
+int part_rows(int rank, int world, int height, int strip_rows);                              // its rows in total
+
 struct Comm;
 // rank 0 creates the id (ncclGetUniqueId; a file-name prefix for the shm transport) and hands it to the other ranks
 bool comm_create_id(void *id128);
@@ -25,6 +36,8 @@ int comm_world(const Comm *c);
 // bands of its rows).  Returns the number of pieces written (at most max_pieces); pure arithmetic.
 struct BandPiece { size_t root_offset, band_offset, bytes; int peer; };
 int band_gather_plan(int world, int root, int width, int height, int nviews, BandPiece *out, int max_pieces);
+// ... for either partition: one piece per (rank, view, segment)
+int part_gather_plan(int world, int root, int width, int height, int nviews, int strip_rows, BandPiece *out, int max_pieces);
 
 // One message of the gather.  On the root: `bytes` from rank `peer` land at `ptr`; elsewhere: `bytes` at `ptr` go to the root.
 struct GatherPiece { void *ptr; size_t bytes; int peer; };

@@ -34,7 +34,6 @@ struct RtTileFrame {
     float4 *tables;
 };
 __global__ void k_tile_tables(const RtTileFrame);
-template <int TW, bool AA> __global__ void k_rt_tile(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile2(const RtTileFrame);
 __global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
 struct TilePairRec { uint32_t tile, beg, nA, nB; };
@@ -250,6 +249,7 @@ struct Ctx {
     char *d_band[2] = { nullptr, nullptr };
     size_t band_bytes[2] = { 0, 0 };
     int band_slot = 0;
+    int strip_rows = 0;                          // partition of a sharded frame: 0 = contiguous bands, > 0 = interleaved strips of that many rows (mirt_set_partition)
 
     // statistics of the last call
     mirt_stats stats = {};
@@ -448,12 +448,11 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         S.known_pairs = *S.h_count; S.have_known = true; S.count_pending = false;
     }
     (void)hipGetLastError();                                 // (hipErrorNotReady of the query is not an error)
-    static const bool always_sync = [] { const char *e = getenv("MIRT_BIN_SYNC"); return e && atoi(e) != 0; }();
     // A pass identical to the one before it (same view, same scene) normally reuses that pass's count without looking; but if
     // that pass was itself a guess and its published count shows the list was too small, the frame fell back to brute force
     // and so would every later frame of this view: treat it as fresh again so that the list grows.
     if (!fresh && may_guess && S.have_known && S.known_pairs > S.cap_used) fresh = true;
-    const bool guess = fresh && may_guess && S.have_known && !always_sync;
+    const bool guess = fresh && may_guess && S.have_known;
     if (!S.d_entries || !S.cap_entries) {
         // first capacity of the pair list (grown on demand below); MIRT_BIN_INITIAL_PAIRS lets a test start small
         static const size_t initial = [] { const char *e = getenv("MIRT_BIN_INITIAL_PAIRS"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : (size_t)1 << 20; }();
@@ -829,14 +828,6 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     }
     hipLaunchKernelGGL(k_tile_order, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, S.d_bin_off, bs.frame0.nshell, bs.frame0.nbu,
                        bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order);
-    if (getenv("MIRT_TR_HIST")) {
-        (void)hipStreamSynchronize(g.stream);
-        uint32_t c[32];
-        (void)hipMemcpy(c, S.d_bin_counters, 128, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[mirt hist] pairs %u | tile pairs by longer list / 16:", c[0]);
-        for (int i = 16; i < 24; i++) fprintf(stderr, " %u", c[i]);
-        fprintf(stderr, "\n");
-    }
     k_end(MIRT_K_BIN);
 
     RtTraceFrame tf;
@@ -862,12 +853,12 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.pair_cap = S.cap_used;
     // one wave per pair of 8 x 8 tiles
     tf.order = S.d_order; tf.order_count = S.d_bin_counters + 16; tf.npairs = npairs;
-    static const int wpb_env = [] { const char *e = getenv("MIRT_TR_WPB"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 1; }();   // (experiments: waves per workgroup)
-    const dim3 tgrid((npairs + (uint32_t)wpb_env - 1u) / (uint32_t)wpb_env);
-    const size_t lds = rt_trace_lds_bytes(wpb_env);
+    // (waves never synchronise with each other: one-wave workgroups are the finest scheduling unit; 84 / 87 / 89 us with 1 / 2 / 4)
+    const dim3 tgrid(npairs);
+    const size_t lds = rt_trace_lds_bytes(1);
     k_begin(MIRT_K_TRACE);
-    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace2<true>, tgrid, dim3(64 * wpb_env), lds, g.stream, tf);
-    else hipLaunchKernelGGL(k_rt_trace2<false>, tgrid, dim3(64 * wpb_env), lds, g.stream, tf);
+    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace2<true>, tgrid, dim3(64), lds, g.stream, tf);
+    else hipLaunchKernelGGL(k_rt_trace2<false>, tgrid, dim3(64), lds, g.stream, tf);
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
@@ -947,8 +938,6 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     // triangles, is above ~4e7: binning + sorting costs ~40 us whatever the scene, brute force ~7.5e-10 ms per pixel-triangle
     // (tools/threshold_sweep.py at 1080p: 65 triangles 0.099 vs 0.043 ms, 300: 0.47 vs 0.079, 800: 1.13 vs 0.097).
     static const int auto_threshold = [] { const char *e = getenv("MIRT_BIN_THRESHOLD"); return e ? atoi(e) : 65; }();
-    // rays per lane of the brute-force / LDS-resident kernels: 2 = packed FP32 filter (188 -> 163 ms on the 100 k soup)
-    static const int P = [] { const char *e = getenv("MIRT_RT_P"); int p = e ? atoi(e) : 2; return (p == 1) ? 1 : 2; }();
     bool binned = (mode == MIRT_RT_BINNED) ||
                   (mode == MIRT_RT_AUTO && g.n >= auto_threshold && (long long)view->width * (y1 - y0) > 4096 &&
                    (long long)view->width * (y1 - y0) * g.n >= 40000000LL);
@@ -964,9 +953,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     // workgroup itself -- no origin-table kernel, no global loads inside the loops.
     // Scenes of at most 64 triangles (the reference's Cornell box has 30): per-tile candidate masks, one lane per
     // triangle (rt_tile.hip).  Needs operands inside the filter's proven range, like binning does.
-    static const int tile_w = [] { const char *e = getenv("MIRT_TILE_W"); int w = e ? atoi(e) : 16; return (w == 8 || w == 16 || w == 64) ? w : 0; }();
     const size_t tile_lds = (size_t)g.n * 16 * (12 + 3 * nlights);
-    const bool tile_path = !binned && safe && tile_w && g.n <= 64 && tile_lds <= 64 * 1024;
+    const bool tile_path = !binned && safe && g.n <= 64 && tile_lds <= 64 * 1024;
 
     // A frame reads the scene and writes the caller's planes plus its stream's own tables, counters and depth-of-field
     // planes, so frames may overlap (call_begin).
@@ -1010,22 +998,15 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         memset(&tf, 0, sizeof tf);
         tf.f = f;
         tf.cam = make_camera_frame(view, y0, y1, g.aa);
-        // two pixels per lane (packed FP32, rt_tile.hip), with or without supersampling; MIRT_TILE_PX=1 keeps one
-        static const int tile_px = [] { const char *e = getenv("MIRT_TILE_PX"); return (e && atoi(e) == 1) ? 1 : 2; }();
-        const bool two = tile_px == 2 && (tile_w == 16 || tile_w == 64);
-        const int tw = two ? ((tile_w == 64 && f.aa <= 1) ? 32 : 16) : tile_w;
-        const int th = (two ? 128 : 64) / tw;
+        // a wave owns a 16 x 8-pixel tile, two pixels per lane (packed FP32, rt_tile.hip); workgroups of 4 waves, one workgroup
+        // per 4 tiles.  Tile cost varies several-fold (candidates, shadowed or lit), and the hardware's dynamic workgroup dispatch
+        // balances that better than any static assignment (measured on the Cornell box at 1080p: 40.5 us with one tile per wave,
+        // 46 us with a resident grid striding over the tiles, 49 us with 3 tiles per wave).
+        const int tw = 16, th = 8, wpb = 4;
         tf.tiles_x = (view->width + tw - 1) / tw;
         tf.tiles_y = (rows + th - 1) / th;
         const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
-        // Workgroups of 4 waves, MIRT_TILE_WGS > 0: that many workgroups per CU, waves stride over the tiles; default: one
-        // workgroup per 4 tiles.  Tile cost varies several-fold (candidates, shadowed or lit), and the hardware's dynamic
-        // workgroup dispatch balances that better than any static assignment (measured on the Cornell box at 1080p:
-        // 40.5 us with one tile per wave, 46 us with a resident grid striding over the tiles, 49 us with 3 tiles per wave).
-        static const int tile_wgs_per_cu = [] { const char *e = getenv("MIRT_TILE_WGS"); int v = e ? atoi(e) : 0; return (v > 0 && v <= 8) ? v : 0; }();
-        static const int tile_waves = [] { const char *e = getenv("MIRT_TILE_WAVES"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 4; }();
-        const int wpb = two ? tile_waves : 4;               // waves per workgroup
-        const unsigned blocks = (unsigned)(tile_wgs_per_cu ? std::min<long long>((ntiles + wpb - 1) / wpb, (long long)g.cu_count * tile_wgs_per_cu) : (ntiles + wpb - 1) / wpb);
+        const unsigned blocks = (unsigned)((ntiles + wpb - 1) / wpb);
         if (!g.hits_clean[g.hits_cur])
             HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
         g.hits_clean[g.hits_cur] = false;
@@ -1035,21 +1016,15 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         g.hits_clean[hits_other] = true;
         // Tables: built once per frame by k_tile_tables when the frame has enough workgroups to make rebuilding them in
         // each one the larger cost; small frames are bound by the launch rate and keep the single launch.
-        static const int tab_blocks = [] { const char *e = getenv("MIRT_TILE_TABLE_BLOCKS"); return e ? atoi(e) : 1024; }();
-        tf.tables = (int)blocks >= tab_blocks ? g.d_tile_tab[si] : nullptr;   // one table buffer per stream
+        tf.tables = blocks >= 1024u ? g.d_tile_tab[si] : nullptr;   // one table buffer per stream
         if (tf.tables) {
             k_begin(MIRT_K_PREP);
             hipLaunchKernelGGL(k_tile_tables, dim3(1), dim3(64), 0, g.stream, tf);
             k_end(MIRT_K_PREP);
         }
         k_begin(MIRT_K_TRACE);
-        if (two && f.aa > 1) hipLaunchKernelGGL((k_rt_tile2<16, true>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
-        else if (f.aa > 1) hipLaunchKernelGGL((k_rt_tile<16, true>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
-        else if (two && tw == 16) hipLaunchKernelGGL((k_rt_tile2<16, false>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
-        else if (two) hipLaunchKernelGGL((k_rt_tile2<32, false>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
-        else if (tile_w == 8) hipLaunchKernelGGL((k_rt_tile<8, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
-        else if (tile_w == 16) hipLaunchKernelGGL((k_rt_tile<16, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
-        else hipLaunchKernelGGL((k_rt_tile<64, false>), dim3(blocks), dim3(256), tile_lds, g.stream, tf);
+        if (f.aa > 1) hipLaunchKernelGGL((k_rt_tile2<16, true>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
+        else hipLaunchKernelGGL((k_rt_tile2<16, false>), dim3(blocks), dim3(64 * wpb), tile_lds, g.stream, tf);
         k_end(MIRT_K_TRACE);
         HIP_TRY(hipGetLastError());
         call_end();
@@ -1061,10 +1036,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
         g.hits_clean[g.hits_cur] = false;
         k_begin(MIRT_K_TRACE);
-        if (P == 2)
-            hipLaunchKernelGGL(k_rt_small<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), small_lds, g.stream, f, safe ? 0 : 1);
-        else
-            hipLaunchKernelGGL(k_rt_small<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), small_lds, g.stream, f, safe ? 0 : 1);
+        // (two rays per lane, packed FP32 filter: 188 -> 163 ms on the 100 k soup against one)
+        hipLaunchKernelGGL(k_rt_small<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), small_lds, g.stream, f, safe ? 0 : 1);
         k_end(MIRT_K_TRACE);
         HIP_TRY(hipGetLastError());
         call_end();
@@ -1094,10 +1067,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     }
     const size_t lds = (size_t)(g.n < RT_CHUNK_ROWS ? g.n : RT_CHUNK_ROWS) * sizeof(OriginRow);
     k_begin(MIRT_K_TRACE);
-    if (P == 2)
-        hipLaunchKernelGGL(k_rt_brute<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), lds, g.stream, f);
-    else
-        hipLaunchKernelGGL(k_rt_brute<1>, dim3((view->width + 63) / 64, (rows + 3) / 4), dim3(256), lds, g.stream, f);
+    hipLaunchKernelGGL(k_rt_brute<2>, dim3((view->width + 127) / 128, (rows + 3) / 4), dim3(256), lds, g.stream, f);
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();
@@ -1755,7 +1725,8 @@ extern "C" int mirt_get_stats(mirt_stats *out)
             g.stats.tests = tests;
             g.stats.candidates = cands;
             g.stats.steps_primary = sp; g.stats.steps_shadow = ss; g.stats.drains = dr;
-            if (getenv("MIRT_TR_TIMING_DUMP")) {
+#ifdef MIRT_TR_TIMING
+            {   // (experiments, rt_trace.hip built with -DMIRT_TR_TIMING: the shard words carry the waves' time per segment)
                 unsigned long long seg[11] = { 0 };
                 for (int i = 0; i < HIT_SHARDS; i++) {
                     for (int k = 0; k < 10; k++) seg[k] += shard[i * HIT_SHARD_STRIDE + 3 + k];
@@ -1764,6 +1735,7 @@ extern "C" int mirt_get_stats(mirt_stats *out)
                 fprintf(stderr, "[mirt timing] Mticks: record %.1f | stage %.1f steps %.1f drains %.1f merge %.1f | light term %.1f offsets+first row %.1f walk %.1f drain %.1f | rest %.1f | longest wave %llu ticks\n",
                         seg[0] * 1e-6, seg[1] * 1e-6, seg[2] * 1e-6, seg[3] * 1e-6, seg[4] * 1e-6, seg[5] * 1e-6, seg[6] * 1e-6, seg[7] * 1e-6, seg[8] * 1e-6, seg[9] * 1e-6, seg[10]);
             }
+#endif
             g.stats.primary_rays = g.pending_primary;
             g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
             if (g.stats.mode_used == MIRT_RT_BRUTE && !g.pending_counted)      // every ray tests every triangle
@@ -1823,6 +1795,43 @@ extern "C" int mirt_band_plan(int world, int root, int width, int height, int nv
     return n;
 }
 
+extern "C" int mirt_set_partition(int strip_rows)
+{
+    if (strip_rows < 0 || (strip_rows % BIN_TILE) != 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "strip height %d must be 0 (bands) or a multiple of %d rows", strip_rows, BIN_TILE);
+    if (g.init) HIP_TRY(sync_all());
+    g.strip_rows = strip_rows;
+    return MIRT_OK;
+}
+
+extern "C" int mirt_partition_segments(int rank, int world, int height, int strip_rows, int32_t *y0, int32_t *y1, int max_segments)
+{
+    if (world < 1 || rank < 0 || rank >= world || height < 0 || strip_rows < 0 || max_segments < 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "segments of rank %d / %d, %d rows, strips of %d", rank, world, height, strip_rows);
+    const int n = part_segments(rank, world, height, strip_rows);
+    for (int k = 0; k < n && k < max_segments; k++) {
+        int a, b;
+        part_segment(rank, world, height, strip_rows, k, &a, &b);
+        if (y0) y0[k] = a;
+        if (y1) y1[k] = b;
+    }
+    return n;
+}
+
+extern "C" int mirt_partition_plan(int world, int root, int width, int height, int nviews, int strip_rows, uint64_t *root_offset, uint64_t *band_offset,
+                                   uint64_t *bytes, int32_t *peer, int max_pieces)
+{
+    if (world < 1 || root < 0 || root >= world || width < 1 || height < 0 || nviews < 1 || max_pieces < 0 || strip_rows < 0)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "partition plan: world %d root %d frame %dx%d views %d strips %d", world, root, width, height, nviews, strip_rows);
+    std::vector<BandPiece> plan((size_t)std::max(max_pieces, 1));
+    const int n = part_gather_plan(world, root, width, height, nviews, strip_rows, plan.data(), max_pieces);
+    for (int i = 0; i < n && i < max_pieces; i++) {
+        if (root_offset) root_offset[i] = plan[i].root_offset;
+        if (band_offset) band_offset[i] = plan[i].band_offset;
+        if (bytes) bytes[i] = plan[i].bytes;
+        if (peer) peer[i] = plan[i].peer;
+    }
+    return n;
+}
+
 extern "C" int mirt_comm_create_id(void *id128)
 {
     if (!id128) return fail(MIRT_ERR_INVALID_ARGUMENT, "id must not be NULL");
@@ -1867,7 +1876,7 @@ extern "C" int mirt_comm_shutdown(void)
 
 // `render(view, y0, y1, row_origin, d_xrgb, pitch)` enqueues one band of one frame on g.stream.
 template <class Render>
-static int render_sharded(const mirt_view *views, int nviews, int root, void *d_frames, int pitch_bytes, Render render)
+static int render_sharded(const mirt_view *views, int nviews, int root, void *d_frames, int pitch_bytes, bool writes_every_word, Render render)
 {
     int rc;
     if ((rc = need_init())) return rc;
@@ -1882,21 +1891,26 @@ static int render_sharded(const mirt_view *views, int nviews, int root, void *d_
     if (rank == root && (pitch_bytes < W * 4 || (pitch_bytes & 3))) return fail(MIRT_ERR_INVALID_ARGUMENT, "pitch %d bytes too small for width %d or not a multiple of 4", pitch_bytes, W);
     if (world > 1 && rank == root && pitch_bytes != W * 4) return fail(MIRT_ERR_INVALID_ARGUMENT, "a sharded frame needs a dense root buffer (pitch == 4 * width)");
     if (world > 1 && g.in_flight != 1) return fail(MIRT_ERR_INVALID_ARGUMENT, "sharded frames overlap through the band buffers: use mirt_set_frames_in_flight(1)");
-    int y0, y1;
-    band_of(rank, world, H, &y0, &y1);
     const size_t frame_bytes = (size_t)H * (size_t)pitch_bytes;
     if (world == 1) {
         for (int v = 0; v < nviews; v++)
             if ((rc = render(&views[v], 0, H, 0, static_cast<char *>(d_frames) + (size_t)v * frame_bytes, pitch_bytes))) return rc;
         return MIRT_OK;
     }
-    const size_t band_row = (size_t)W * 4, my_bytes = (size_t)(y1 - y0) * band_row;
+    // this rank's rows: one contiguous band, or interleaved strips (mirt_set_partition) -- a band buffer holds the segments of
+    // one view back to back
+    const int segs = part_segments(rank, world, H, g.strip_rows);
+    const size_t band_row = (size_t)W * 4, my_bytes = (size_t)part_rows(rank, world, H, g.strip_rows) * band_row;
     const int slot = g.band_slot;
     g.band_slot ^= 1;
     if (rank == root) {
-        // the root's own rows are rendered in place; the other bands arrive straight at their rows
+        // the root's own rows are rendered in place; the other ranks' rows arrive straight at their places
         for (int v = 0; v < nviews; v++)
-            if ((rc = render(&views[v], y0, y1, 0, static_cast<char *>(d_frames) + (size_t)v * frame_bytes, pitch_bytes))) return rc;
+            for (int k = 0; k < segs; k++) {
+                int y0, y1;
+                part_segment(rank, world, H, g.strip_rows, k, &y0, &y1);
+                if (y1 > y0 && (rc = render(&views[v], y0, y1, 0, static_cast<char *>(d_frames) + (size_t)v * frame_bytes, pitch_bytes))) return rc;
+            }
     } else {
         const size_t need = my_bytes * (size_t)nviews;
         HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_sent[slot], 0));         // the gather that last read this buffer has finished
@@ -1905,19 +1919,31 @@ static int render_sharded(const mirt_view *views, int nviews, int root, void *d_
             if (g.d_band[slot]) (void)hipFree(g.d_band[slot]);
             g.d_band[slot] = nullptr; g.band_bytes[slot] = 0;
             if (hipMalloc(reinterpret_cast<void **>(&g.d_band[slot]), need) != hipSuccess) return fail(MIRT_ERR_OUT_OF_MEMORY, "band buffer (%zu bytes)", need);
-            HIP_TRY(hipMemsetAsync(g.d_band[slot], 0, need, g.stream));   // the border words the ray tracer never writes travel as 0
             g.band_bytes[slot] = need;
         }
-        for (int v = 0; v < nviews; v++)
-            if ((rc = render(&views[v], y0, y1, y0, g.d_band[slot] + (size_t)v * my_bytes, (int)band_row))) return rc;
+        // the border words the ray tracer never writes travel as 0, whatever the buffer held before (a rasterised batch, a
+        // batch of another frame size)
+        if (!writes_every_word && need) HIP_TRY(hipMemsetAsync(g.d_band[slot], 0, need, g.stream));
+        for (int v = 0; v < nviews; v++) {
+            int before = 0;                                  // rows of this view's earlier segments in the band buffer
+            for (int k = 0; k < segs; k++) {
+                int y0, y1;
+                part_segment(rank, world, H, g.strip_rows, k, &y0, &y1);
+                // (row y of the segment lands at row before + (y - y0) of this view's part of the buffer)
+                if (y1 > y0 && (rc = render(&views[v], y0, y1, y0 - before, g.d_band[slot] + (size_t)v * my_bytes, (int)band_row))) return rc;
+                before += y1 - y0;
+            }
+        }
     }
     // the one exchange step: every band to the root, on the communication stream, overlapping the next call's render
     HIP_TRY(hipEventRecord(g.ev_rendered, g.stream));
     HIP_TRY(hipStreamWaitEvent(g.comm_stream, g.ev_rendered, 0));
-    std::vector<BandPiece> plan((size_t)world * nviews);
-    const int np = band_gather_plan(world, root, W, H, nviews, plan.data(), (int)plan.size());
+    const int maxp = part_gather_plan(world, root, W, H, nviews, g.strip_rows, nullptr, 0);
+    std::vector<BandPiece> plan((size_t)std::max(maxp, 1));
+    const int np = part_gather_plan(world, root, W, H, nviews, g.strip_rows, plan.data(), (int)plan.size());
     std::vector<GatherPiece> pieces;
     for (int i = 0; i < np; i++) {
+        if (plan[i].bytes == 0) continue;
         if (rank == root) pieces.push_back({ static_cast<char *>(d_frames) + plan[i].root_offset, plan[i].bytes, plan[i].peer });
         else if (plan[i].peer == rank) pieces.push_back({ g.d_band[slot] + plan[i].band_offset, plan[i].bytes, root });
     }
@@ -1930,7 +1956,7 @@ static int render_sharded(const mirt_view *views, int nviews, int root, void *d_
 extern "C" int mirt_raytrace_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,
                                      int mode, int root, void *d_frames, int pitch_bytes)
 {
-    return render_sharded(views, nviews, root, d_frames, pitch_bytes, [&](const mirt_view *v, int y0, int y1, int origin, void *dst, int pitch) {
+    return render_sharded(views, nviews, root, d_frames, pitch_bytes, false, [&](const mirt_view *v, int y0, int y1, int origin, void *dst, int pitch) {
         return mirt_raytrace_device(v, lights, nlights, indirect, mode, y0, y1, origin, dst, pitch, nullptr, nullptr);
     });
 }
@@ -1938,7 +1964,7 @@ extern "C" int mirt_raytrace_sharded(const mirt_view *views, int nviews, const m
 extern "C" int mirt_rasterise_sharded(const mirt_view *views, int nviews, const mirt_light *lights, int nlights, const float *indirect,
                                       int root, void *d_frames, int pitch_bytes)
 {
-    return render_sharded(views, nviews, root, d_frames, pitch_bytes, [&](const mirt_view *v, int y0, int y1, int origin, void *dst, int pitch) {
+    return render_sharded(views, nviews, root, d_frames, pitch_bytes, true, [&](const mirt_view *v, int y0, int y1, int origin, void *dst, int pitch) {
         return mirt_rasterise_device(v, lights, nlights, indirect, y0, y1, origin, dst, pitch, nullptr, nullptr, nullptr);
     });
 }

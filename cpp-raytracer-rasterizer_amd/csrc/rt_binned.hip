@@ -456,19 +456,4 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
 #endif
 }
 
-// bin_off[b] = first position of a key >= b in the sorted pair list (b = 0 .. nbins; bin_off[nbins] = total)
-__global__ __launch_bounds__(256) void k_bin_offsets(const uint32_t *__restrict__ sorted_keys, const uint32_t *__restrict__ total_ptr,
-                                                     uint32_t cap, uint32_t nbins, uint32_t *__restrict__ bin_off)
-{
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nbins) return;
-    const uint32_t total = min(*total_ptr, cap);
-    uint32_t lo = 0, hi = total;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (sorted_keys[mid] < b) lo = mid + 1; else hi = mid;
-    }
-    bin_off[b] = lo;
-}
-
 }  // namespace mirt

@@ -166,13 +166,27 @@ __device__ __forceinline__ f2 maybe_hit2_margin(const TestDots2 &d)
     return (f2){ fminf(fminf(a.x, b.x), slack.x), fminf(fminf(a.y, b.y), slack.y) };
 }
 
+// The directions of the P rays of a lane: one by one, and -- P == 2 -- as the pairs the packed dot products want, built
+// component by component as the directions are computed (pairing the two array elements inside the triangle loop made the
+// compiler hoist the pairing through 48 bytes of scratch).
+template <int P> struct RayDirs {
+    v3 s[P];
+    v3p pk;
+    __device__ __forceinline__ void set(int p, v3 n)
+    {
+        s[p] = n;
+        if constexpr (P == 2) { pk.x[p] = n.x; pk.y[p] = n.y; pk.z[p] = n.z; }
+    }
+};
+
 // Dots and filter verdicts of P rays against one origin row: packed when P == 2 and the filter is on.
 template <int P, bool FILTER>
-__device__ __forceinline__ void test_rays(const float4 &r0, const float4 &r1, const float4 &r2, const v3 (&nd)[P],
+__device__ __forceinline__ void test_rays(const float4 &r0, const float4 &r1, const float4 &r2, const RayDirs<P> &rays,
                                           TestDots (&d)[P], bool (&maybe)[P])
 {
+    const v3 (&nd)[P] = rays.s;
     if constexpr (P == 2 && FILTER) {
-        const TestDots2 t = test_dots2(r0, r1, r2, join3(nd[0], nd[1]));
+        const TestDots2 t = test_dots2(r0, r1, r2, rays.pk);
         maybe_hit2(t, &maybe[0], &maybe[1]);
         d[0] = dots_half(t, 0);
         d[1] = dots_half(t, 1);

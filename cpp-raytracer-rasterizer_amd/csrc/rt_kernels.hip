@@ -77,13 +77,13 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab, int 
 #pragma unroll
         for (int p = 0; p < P; p++) x1[p] = aa_start(xs[p], rs);          // :573-576
         for (int z2 = 0; z2 < rs; z2++) {
-            v3 nd[P];
+            RayDirs<P> nd;
             bool any[P];
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 // d = (x1 - W/2, y1 - H/2, focalLength); dir = cameraRot * d   (raytracer.cpp:579-580)
                 const v3 d = V3(x1[p] - halfW, y1 - halfH, f.focal);
-                nd[p] = neg3(mat3_mul_vec(f.rot, d));     // negD = -dir (:229)
+                nd.set(p, neg3(mat3_mul_vec(f.rot, d)));  // negD = -dir (:229)
                 any[p] = false;
             }
 
@@ -138,14 +138,17 @@ __device__ __forceinline__ void brute_body(const RtFrame &f, float4 *s_tab, int 
 
             for (int k = 0; k < f.nlights; k++) {
                 const v3 L = ld3(f.lpos[k]);
-                v3 D[P], rd[P];
+                v3 D[P];
+                RayDirs<P> rd;
                 float thr[P];
                 bool live[P];      // still needs shadow testing
                 bool any_live = false;
 #pragma unroll
                 for (int p = 0; p < P; p++) {
                     float r;
-                    D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
+                    v3 rdp;
+                    D[p] = light_term(f, k, pos[p], nDir[p], &rdp, &r);
+                    rd.set(p, rdp);
                     thr[p] = r * 0.99f;                    // j.distance < r*0.99f (:313)
                     live[p] = hit[p];
                     any_live |= live[p];
@@ -275,12 +278,12 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
 #pragma unroll
         for (int p = 0; p < P; p++) x1[p] = aa_start(xs[p], rs);            // :573-576
         for (int z2 = 0; z2 < rs; z2++) {
-            v3 nd[P];
+            RayDirs<P> nd;
             bool any[P];
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const v3 d = V3(x1[p] - halfW, y1 - halfH, f.focal);        // raytracer.cpp:579
-                nd[p] = neg3(mat3_mul_vec(f.rot, d));                        // :580, :229
+                nd.set(p, neg3(mat3_mul_vec(f.rot, d)));                     // :580, :229
                 any[p] = false;
             }
 #pragma unroll 2
@@ -325,13 +328,16 @@ __device__ __forceinline__ void small_body(const RtFrame &f, const float4 *s_cam
             for (int k = 0; k < f.nlights; k++) {
                 const v3 L = ld3(f.lpos[k]);
                 const float4 *tab = s_light + (size_t)3 * n * k;
-                v3 D[P], rd[P];
+                v3 D[P];
+                RayDirs<P> rd;
                 float thr[P];
                 bool live[P];
 #pragma unroll
                 for (int p = 0; p < P; p++) {
                     float r;
-                    D[p] = light_term(f, k, pos[p], nDir[p], &rd[p], &r);
+                    v3 rdp;
+                    D[p] = light_term(f, k, pos[p], nDir[p], &rdp, &r);
+                    rd.set(p, rdp);
                     thr[p] = r * 0.99f;                                      // :313
                     live[p] = hit[p];
                 }
@@ -427,7 +433,6 @@ __global__ __launch_bounds__(256) void k_rt_small(const RtFrame f, int host_unsa
     }
 }
 
-template __global__ void k_rt_small<1>(const RtFrame, int);
 template __global__ void k_rt_small<2>(const RtFrame, int);
 
 // ---- k_rt_wave: one WAVE per ray, lanes over triangles, wavefront min-t reduce ----------------------------
@@ -541,7 +546,6 @@ __global__ __launch_bounds__(256) void k_rt_brute(const RtFrame f)
     }
 }
 
-template __global__ void k_rt_brute<1>(const RtFrame);
 template __global__ void k_rt_brute<2>(const RtFrame);
 
 }  // namespace mirt

@@ -2,9 +2,9 @@
 // everything lives in LDS and every wave prunes the triangle list for its tile before it walks it.
 //
 // k_rt_small (rt_kernels.hip) already keeps the whole scene in LDS, but each of its rays still runs the filter
-// against all n triangles, twice (primary + shadow).  Here a wave owns a pixel tile -- 16 x 8 with two pixels per lane
-// (tile_body2, packed FP32, the default) or TW x (64/TW) with one (tile_body) -- and first builds two 64-bit candidate
-// masks with ONE lane per triangle:
+// against all n triangles, twice (primary + shadow).  Here a wave owns a 16 x 8-pixel tile, two pixels per lane in packed
+// FP32 (tile_body2; round 1's one-pixel-per-lane form, 7 % slower, is gone), and first builds two 64-bit candidate masks
+// with ONE lane per triangle:
 //   * primary rays: the conservative rectangle test of rt_binned.hpp (affine edge functions of the camera frame
 //     over the tile's pixel rectangle);
 //   * shadow rays of light k: the same sign conditions evaluated with interval arithmetic over the bounding box of
@@ -56,22 +56,8 @@ __device__ __forceinline__ bool box_may_hit(const float4 &r0, const float4 &r1, 
     return pos || neg;
 }
 
-__device__ __forceinline__ bool exact_hit_geo(const TestDots &d, float e1e2b, const float4 *geo, v3 start, v3 *pos, float *dist)
-{
-    const float t = e1e2b / d.den, u = d.pu / d.den, v = d.qv / d.den;      // raytracer.cpp:237
-    if (u + v <= 1.0f && u >= 0.0f && v >= 0.0f && t >= 0.0f) {             // :239
-        const float4 g0 = geo[0], g1 = geo[1], g2 = geo[2];
-        const v3 v0 = V3(g0.x, g0.y, g0.z), e1 = V3(g0.w, g1.x, g1.y), e2 = V3(g1.z, g1.w, g2.x);
-        const v3 p = add3(add3(v0, scale3(e1, u)), scale3(e2, v));          // :241
-        *pos = p;
-        *dist = distance3(start, p);                                         // :242
-        return true;
-    }
-    return false;
-}
-
-// The same for the two pixels of a lane at once (k_rt_tile2): the six divisions as three packed pairs, the triangle's geometry
-// read once, hit points and distances in packed arithmetic -- operation for operation what exact_hit_geo does per half.  A half
+// The accept test and hit point (raytracer.cpp:237-242) for the two pixels of a lane at once (k_rt_tile2): the six divisions as three packed pairs, the triangle's geometry
+// read once, hit points and distances in packed arithmetic -- operation for operation what exact_hit (rt_common.hpp) does per half.  A half
 // the filter rejected computes values nobody reads (its `m` is false), like an inactive lane.
 __device__ __forceinline__ void exact_hit_geo2(const TestDots2 &d, float e1e2b, const float4 *geo, v3 start, bool m0, bool m1,
                                                bool *hit0, bool *hit1, v3p *pos, f2 *dist)
@@ -87,129 +73,6 @@ __device__ __forceinline__ void exact_hit_geo2(const TestDots2 &d, float e1e2b, 
         *pos = p;
         *dist = distance3p(splat3(start), p);                                                    // :242
     }
-}
-
-template <int TW, bool AA>
-__device__ __forceinline__ void tile_body(const RtTileFrame &tf, int tx, int ty, const float4 *s_cam, const float4 *s_geo,
-                                          const float4 *s_fns, const float4 *s_shade, const float4 *s_light)
-{
-    constexpr int TH = 64 / TW;
-    const RtFrame &f = tf.f;
-    const int lane = threadIdx.x & 63, n = f.n;
-    const int x0 = tx * TW, y0 = f.y0 + ty * TH;
-    const int x = x0 + (lane % TW), y = y0 + (lane / TW);
-    const bool ok = x < f.W && y < f.y1;
-    const v3 cam = ld3(f.cam);
-
-    // ---- primary candidates: one lane per triangle tests the tile's pixel rectangle ----
-    // (with supersampling the sub-rays reach half a pixel beyond the pixel centres on every side)
-    const int rs = AA ? f.aa : 1;                 // compile-time 1 without supersampling: the loops below fold away
-    const float reach = rs > 1 ? 0.5f : 0.0f;
-    bool cand = false;
-    if (lane < n) {
-        TriBinFns t;
-        const float4 a = s_fns[4 * lane], b = s_fns[4 * lane + 1], c = s_fns[4 * lane + 2], d4 = s_fns[4 * lane + 3];
-        t.n.c0 = a.x; t.n.cu = a.y; t.n.cv = a.z; t.n.m = a.w;
-        t.p.c0 = b.x; t.p.cu = b.y; t.p.cv = b.z; t.p.m = b.w;
-        t.q.c0 = c.x; t.q.cu = c.y; t.q.cv = c.z; t.q.m = c.w;
-        t.s.c0 = d4.x; t.s.cu = d4.y; t.s.cv = d4.z; t.s.m = d4.w;
-        t.nb = s_cam[3 * lane].w;
-        t.bstate = BOX_NONE; t.bu0 = t.bu1 = t.bv0 = t.bv1 = 0.0f;
-        cand = rect_may_hit(t, (float)x0 - reach, (float)min(x0 + TW - 1, f.W - 1) + reach,
-                            (float)y0 - reach, (float)min(y0 + TH - 1, f.y1 - 1) + reach);
-    }
-    const unsigned long long pmask = __ballot(cand);
-    unsigned ntests = 0;                                                     // ray-triangle tests this lane runs
-
-    float best_d = FLT_MAX;                                                  // Update() reset (:335-339), once per frame
-    int best_i = -1;
-    v3 pos = V3(0.0f, 0.0f, 0.0f);
-    v3 avg = V3(0.0f, 0.0f, 0.0f);
-    float y1 = aa_start(y, rs);                                              // :566-569
-    for (int z = 0; z < rs; z++) {
-        float x1 = aa_start(x, rs);                                          // :573-576
-        for (int z2 = 0; z2 < rs; z2++) {
-            // d = (x1 - W/2, y1 - H/2, focalLength); negD = -(cameraRot * d)   (raytracer.cpp:579-580, :229)
-            const v3 d = V3(x1 - (float)f.W / 2.0f, y1 - (float)f.H / 2.0f, f.focal);
-            const v3 nd = neg3(mat3_mul_vec(f.rot, d));
-            bool any = false;                                                // ClosestIntersection's return value
-            unsigned long long pm = pmask;
-            if (ok) ntests += (unsigned)__popcll(pm);
-            while (pm) {                                                     // ascending index: the `>=` rule holds
-                const int j = __builtin_ctzll(pm);
-                pm &= pm - 1ull;
-                const float4 r0 = s_cam[3 * j], r1 = s_cam[3 * j + 1], r2 = s_cam[3 * j + 2];
-                const TestDots td = test_dots(r0, r1, r2, nd);
-                if (maybe_hit(td)) {
-                    v3 hp;
-                    float dist;
-                    if (exact_hit_geo(td, r0.w, s_geo + 3 * j, cam, &hp, &dist)) {
-                        any = true;
-                        if (best_d >= dist) { best_d = dist; best_i = j; pos = hp; }     // :243-247 (carried across sub-rays)
-                    }
-                }
-            }
-            const bool hit = ok && any;
-            count_hits(f, (unsigned long long)__popcll(__ballot(hit)));
-
-            if (__any(hit)) {
-                const int bi = best_i >= 0 ? best_i : 0;
-                const float4 sh0 = s_shade[2 * bi], sh1 = s_shade[2 * bi + 1];
-                const v3 nDir = V3(sh0.x, sh0.y, sh0.z);                     // glm::normalize(normal) (:300), per triangle
-                const v3 tcol = V3(sh1.x, sh1.y, sh1.z);
-                v3 result = V3(0.0f, 0.0f, 0.0f), result2 = V3(0.0f, 0.0f, 0.0f);
-                for (int k = 0; k < f.nlights; k++) {
-                    const v3 L = ld3(f.lpos[k]);
-                    v3 rd;
-                    float r;
-                    v3 D = light_term(f, k, pos, nDir, &rd, &r);
-                    const float thr = r * 0.99f;                             // :313
-                    const float4 *tab = s_light + (size_t)3 * n * k;
-                    // ---- shadow candidates: direction box of the wave's live rays, one lane per triangle ----
-                    const float inf = __builtin_huge_valf();
-                    const v3 lo = V3(wave_min_f(hit ? rd.x : inf), wave_min_f(hit ? rd.y : inf), wave_min_f(hit ? rd.z : inf));
-                    const v3 hi = V3(wave_max_f(hit ? rd.x : -inf), wave_max_f(hit ? rd.y : -inf), wave_max_f(hit ? rd.z : -inf));
-                    bool sc = false;
-                    if (lane < n) sc = box_may_hit(tab[3 * lane], tab[3 * lane + 1], tab[3 * lane + 2], lo, hi);
-                    unsigned long long sm = __ballot(sc);
-                    if (hit) ntests += (unsigned)__popcll(sm);
-                    bool live = hit;
-                    while (sm) {
-                        const int j = __builtin_ctzll(sm);
-                        sm &= sm - 1ull;
-                        const float4 r0 = tab[3 * j], r1 = tab[3 * j + 1], r2 = tab[3 * j + 2];
-                        const TestDots td = test_dots(r0, r1, r2, rd);       // negD = rDir (:310, :229)
-                        if (live && maybe_hit(td)) {
-                            v3 hp;
-                            float dist;
-                            if (exact_hit_geo(td, r0.w, s_geo + 3 * j, L, &hp, &dist) && dist < thr) {
-                                live = false;                                 // occluded (:313-314); any-hit is exact
-                                D = V3(0.0f, 0.0f, 0.0f);
-                            }
-                        }
-                    }
-                    result = add3(result, D);                                // :319
-                    if ((k + 1) % f.samples == 0) result2 = add3(result2, result);   // :322, after each light's samples
-                }
-                if (hit) {
-                    const v3 Dl = mul3(result2, tcol);                       // :325-326
-                    avg = add3(avg, mul3(tcol, add3(Dl, ld3(f.indirect))));  // :584-591
-                    x1 += aa_step(rs);                                       // :593, only after a hit
-                }
-            }
-        }
-        y1 += aa_step(rs);                                                   // :596
-    }
-    count_tests(f, ntests);
-    if (!ok) return;
-    avg = div3s(avg, (float)(rs * rs));                                      // :599
-    const size_t px = (size_t)y * f.W + x;
-    if (f.rgb) st3(f.rgb + 3 * px, avg);
-    if (f.index) f.index[px] = best_i;
-    if (f.fd) f.fd[px] = best_i >= 0 ? best_d - f.focal_plane : 0.0f;          // focalDistances (:248-249)
-    store_intersection(f, px, best_i, best_d, pos);
-    if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1)                      // :618-620
-        f.xrgb[(size_t)(y - f.row_origin) * f.pitch_words + x] = pack_xrgb(avg);
 }
 
 // Per-frame tables of the tile kernels: origin rows of the camera and of every light position, geometry, the
@@ -280,19 +143,6 @@ __device__ __forceinline__ TileTables tile_tables_load(const RtTileFrame &tf, fl
     tb.light = tb.shade + 2 * n;
     return tb;
 }
-
-template <int TW, bool AA>
-__global__ __launch_bounds__(256) void k_rt_tile(const RtTileFrame tf)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 s_all[];
-    const TileTables tab = tile_tables_load(tf, s_all);
-    const float4 *s_cam = tab.cam, *s_geo = tab.geo, *s_fns = tab.fns, *s_shade = tab.shade, *s_light = tab.light;
-    // one tile per wave when the grid covers the frame (the default, see mirt_capi.hip); a smaller grid strides
-    const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
-    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * 4)
-        tile_body<TW, AA>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), s_cam, s_geo, s_fns, s_shade, s_light);
-}
-
 
 // ---- two pixels per lane -------------------------------------------------------------------------------------------
 // The same tile algorithm with a wave owning TW x (128/TW) pixels: lane l carries pixel (lx, ly) and the pixel
@@ -471,7 +321,7 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
 }
 
 template <int TW, bool AA>
-__global__ __launch_bounds__(1024) void k_rt_tile2(const RtTileFrame tf)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rt_tile2(const RtTileFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
     const TileTables tab = tile_tables_load(tf, s_all);
@@ -482,12 +332,6 @@ __global__ __launch_bounds__(1024) void k_rt_tile2(const RtTileFrame tf)
 }
 
 template __global__ void k_rt_tile2<16, false>(const RtTileFrame);
-template __global__ void k_rt_tile2<32, false>(const RtTileFrame);
 template __global__ void k_rt_tile2<16, true>(const RtTileFrame);
-
-template __global__ void k_rt_tile<8, false>(const RtTileFrame);
-template __global__ void k_rt_tile<16, false>(const RtTileFrame);
-template __global__ void k_rt_tile<64, false>(const RtTileFrame);
-template __global__ void k_rt_tile<16, true>(const RtTileFrame);
 
 }  // namespace mirt

@@ -288,11 +288,16 @@ __global__ __launch_bounds__(256) void k_tile_order(const uint32_t *__restrict__
     }
 }
 
+// waves per SIMD the register allocator aims for: 4 (<= 128 VGPRs) -- the supersampling variant, which carries a second set of
+// sub-ray state, may take 3 rather than spill
 #ifndef MIRT_TR_WAVES
 #define MIRT_TR_WAVES 4
 #endif
+#ifndef MIRT_TR_WAVES_MIN
+#define MIRT_TR_WAVES_MIN 3
+#endif
 template <bool AA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAVES, MIRT_TR_WAVES))) void k_rt_trace2(const RtTraceFrame tf)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAVES_MIN, MIRT_TR_WAVES))) void k_rt_trace2(const RtTraceFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
     const RtFrame &f = tf.f;

@@ -22,7 +22,7 @@ EXPORTS = (
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
     "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats", "mirt_get_previous_kernel_ms", "mirt_surface_register", "mirt_surface_unregister", "mirt_raytrace_async", "mirt_rasterise_async",
-    "mirt_band_of", "mirt_band_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_comm_selfcheck", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
+    "mirt_band_of", "mirt_band_plan", "mirt_set_partition", "mirt_partition_segments", "mirt_partition_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_comm_selfcheck", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
 )
 
 
@@ -89,6 +89,9 @@ def load():
     lib.mirt_rasterise_async.argtypes = [C.POINTER(View), _vp, C.c_int, _vp, _vp, C.c_int]
     lib.mirt_band_of.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mirt_band_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]
+    lib.mirt_set_partition.argtypes = [C.c_int]
+    lib.mirt_partition_segments.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
+    lib.mirt_partition_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]
     lib.mirt_comm_create_id.argtypes = [_vp]
     lib.mirt_comm_init.argtypes = [_vp, C.c_int, C.c_int]
     lib.mirt_comm_selfcheck.argtypes = [C.c_size_t]
@@ -400,6 +403,31 @@ def band_plan(world, root, width, height, nviews):
     ro, bo, by, pe = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.int32)
     load().mirt_band_plan(world, root, width, height, nviews, _ptr(ro), _ptr(bo), _ptr(by), _ptr(pe), n)
     return [(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(ro, bo, by, pe)]
+
+
+def set_partition(strip_rows):
+    """0: contiguous bands; > 0: interleaved strips of that many rows (mirt_set_partition)."""
+    _check(load().mirt_set_partition(int(strip_rows)))
+
+
+def partition_segments(rank, world, height, strip_rows):
+    """[(y0, y1)] of a rank's rows (mirt_partition_segments)."""
+    n = load().mirt_partition_segments(rank, world, height, strip_rows, None, None, 0)
+    if n < 0:
+        _check(n)
+    a, b = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    load().mirt_partition_segments(rank, world, height, strip_rows, _ptr(a), _ptr(b), n)
+    return [(int(x), int(y)) for x, y in zip(a[:n], b[:n])]
+
+
+def partition_plan(world, root, width, height, nviews, strip_rows):
+    """[(root_offset, band_offset, bytes, peer)] of one gather for either partition (mirt_partition_plan)."""
+    n = load().mirt_partition_plan(world, root, width, height, nviews, strip_rows, None, None, None, None, 0)
+    if n < 0:
+        _check(n)
+    ro, bo, by, pe = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.int32)
+    load().mirt_partition_plan(world, root, width, height, nviews, strip_rows, _ptr(ro), _ptr(bo), _ptr(by), _ptr(pe), n)
+    return [(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(ro[:n], bo[:n], by[:n], pe[:n])]
 
 
 def comm_create_id():

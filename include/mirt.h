@@ -277,6 +277,20 @@ MIRT_API int mirt_band_of(int rank, int world, int height, int *y0, int *y1);
  * of pieces (writes at most max_pieces; arrays nullable).  Pure arithmetic, no device needed. */
 MIRT_API int mirt_band_plan(int world, int root, int width, int height, int nviews, uint64_t *root_offset, uint64_t *band_offset,
                             uint64_t *bytes, int32_t *peer, int max_pieces);
+/* The partition of a sharded frame among the ranks (every rank must set the same; default 0):
+ *   strip_rows == 0   contiguous bands (mirt_band_of): one binning pass and one launch chain per rank and frame -- the right
+ *                     choice for the binned ray tracer, whose per-frame cost has a part that does not shrink with the rows;
+ *   strip_rows  > 0   interleaved strips of that many rows (a multiple of 8), strip s to rank s % world: every rank samples the
+ *                     whole height of the frame, which evens out scenes whose cost is concentrated in some rows -- what the
+ *                     reference's `#pragma omp parallel for schedule(auto)` over rows does (raytracer.cpp:557, rasteriser.cpp:467),
+ *                     at the granularity a GPU launch needs (64).  Each strip is a launch chain of its own.
+ * mirt_partition_segments / mirt_partition_plan: a rank's row segments [y0[k], y1[k]) and the gather's messages for either
+ * partition (mirt_band_of / mirt_band_plan are the strip_rows == 0 case); a band buffer holds a rank's segments of one view back
+ * to back.  Pure arithmetic, no device needed; both return the count (arrays nullable, at most max_* entries written). */
+MIRT_API int mirt_set_partition(int strip_rows);
+MIRT_API int mirt_partition_segments(int rank, int world, int height, int strip_rows, int32_t *y0, int32_t *y1, int max_segments);
+MIRT_API int mirt_partition_plan(int world, int root, int width, int height, int nviews, int strip_rows, uint64_t *root_offset,
+                                 uint64_t *band_offset, uint64_t *bytes, int32_t *peer, int max_pieces);
 MIRT_API int mirt_comm_create_id(void *id128);
 MIRT_API int mirt_comm_init(const void *id128, int rank, int world);
 MIRT_API int mirt_comm_shutdown(void);

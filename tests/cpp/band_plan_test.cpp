@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -15,10 +16,11 @@ using namespace mirt;
 
 static uint32_t pattern(int view, int y, int x) { return 0x9E3779B9u * (uint32_t)(view + 1) ^ (uint32_t)(y * 40503 + x * 65599 + 17); }
 
-static bool run(int world, int root, int W, int H, int nviews)
+// strip == 0: contiguous bands; > 0: interleaved strips of that many rows
+static bool run(int world, int root, int W, int H, int nviews, int strip = 0)
 {
-    std::vector<BandPiece> plan((size_t)world * nviews);
-    const int np = band_gather_plan(world, root, W, H, nviews, plan.data(), (int)plan.size());
+    std::vector<BandPiece> plan((size_t)std::max(1, part_gather_plan(world, root, W, H, nviews, strip, nullptr, 0)));
+    const int np = part_gather_plan(world, root, W, H, nviews, strip, plan.data(), (int)plan.size());
     std::vector<int> rd(world, -1), wr(world, -1);
     std::vector<pid_t> pids;
     for (int r = 0; r < world; r++) {
@@ -28,12 +30,19 @@ static bool run(int world, int root, int W, int H, int nviews)
         const pid_t pid = fork();
         if (pid == 0) {                                   // rank r: render my band of every view, send the pieces the plan gives me
             close(fd[0]);
-            int y0, y1;
-            band_of(r, world, H, &y0, &y1);
-            std::vector<uint32_t> band((size_t)nviews * (y1 - y0) * W);
-            for (int v = 0; v < nviews; v++)
-                for (int y = y0; y < y1; y++)
-                    for (int x = 0; x < W; x++) band[((size_t)v * (y1 - y0) + (y - y0)) * W + x] = pattern(v, y, x);
+            // the band buffer: this rank's segments of one view back to back, views one after the other
+            const int mine = part_rows(r, world, H, strip), segs = part_segments(r, world, H, strip);
+            std::vector<uint32_t> band((size_t)nviews * mine * W + 1);
+            for (int v = 0; v < nviews; v++) {
+                int before = 0;
+                for (int k = 0; k < segs; k++) {
+                    int y0, y1;
+                    part_segment(r, world, H, strip, k, &y0, &y1);
+                    for (int y = y0; y < y1; y++)
+                        for (int x = 0; x < W; x++) band[((size_t)v * mine + before + (y - y0)) * W + x] = pattern(v, y, x);
+                    before += y1 - y0;
+                }
+            }
             for (int i = 0; i < np; i++)
                 if (plan[i].peer == r) {
                     const char *p = reinterpret_cast<const char *>(band.data()) + plan[i].band_offset;
@@ -49,11 +58,13 @@ static bool run(int world, int root, int W, int H, int nviews)
     }
     // the root: its own rows in place, the other bands where the plan puts them
     std::vector<uint32_t> frames((size_t)nviews * H * W, 0xDEADBEEFu);
-    int y0, y1;
-    band_of(root, world, H, &y0, &y1);
-    for (int v = 0; v < nviews; v++)
-        for (int y = y0; y < y1; y++)
-            for (int x = 0; x < W; x++) frames[((size_t)v * H + y) * W + x] = pattern(v, y, x);
+    for (int k = 0, segs = part_segments(root, world, H, strip); k < segs; k++) {
+        int y0, y1;
+        part_segment(root, world, H, strip, k, &y0, &y1);
+        for (int v = 0; v < nviews; v++)
+            for (int y = y0; y < y1; y++)
+                for (int x = 0; x < W; x++) frames[((size_t)v * H + y) * W + x] = pattern(v, y, x);
+    }
     bool ok = true;
     for (int i = 0; i < np && ok; i++) {
         char *p = reinterpret_cast<char *>(frames.data()) + plan[i].root_offset;
@@ -66,6 +77,7 @@ static bool run(int world, int root, int W, int H, int nviews)
         for (int y = 0; y < H && ok; y++)
             for (int x = 0; x < W; x++)
                 if (frames[((size_t)v * H + y) * W + x] != pattern(v, y, x)) { ok = false; fprintf(stderr, "world %d root %d: frame %d (%d,%d) wrong\n", world, root, v, x, y); break; }
+    if (strip > 0) return ok;
     // the bands tile [0, H) in rank order
     int next = 0;
     for (int r = 0; r < world; r++) { int a, b; band_of(r, world, H, &a, &b); ok = ok && a == next && b >= a && b - a <= H / world + 1; next = b; }
@@ -77,6 +89,9 @@ int main()
     const int cases[][5] = { { 2, 0, 64, 48, 1 }, { 2, 1, 33, 7, 3 }, { 3, 0, 20, 10, 2 }, { 3, 2, 17, 2, 1 }, { 5, 3, 9, 23, 4 }, { 1, 0, 8, 8, 2 }, { 4, 0, 5, 3, 2 } };
     for (const auto &c : cases)
         if (!run(c[0], c[1], c[2], c[3], c[4])) { printf("FAILED world %d root %d %dx%d views %d\n", c[0], c[1], c[2], c[3], c[4]); return 1; }
+    const int strips[][6] = { { 2, 0, 16, 40, 1, 8 }, { 3, 1, 7, 100, 2, 16 }, { 5, 4, 3, 9, 1, 8 }, { 4, 2, 5, 64, 3, 64 }, { 8, 0, 6, 432, 2, 64 } };
+    for (const auto &c : strips)
+        if (!run(c[0], c[1], c[2], c[3], c[4], c[5])) { printf("FAILED strips world %d root %d %dx%d views %d strip %d\n", c[0], c[1], c[2], c[3], c[4], c[5]); return 1; }
     printf("ok\n");
     return 0;
 }

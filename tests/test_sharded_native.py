@@ -52,6 +52,36 @@ def test_gather_plan_assembles_frames(world, root, W, H, nviews):
     assert sum(p[2] for p in plan) == (H - (y1 - y0)) * W * 4 * nviews
 
 
+@pytest.mark.parametrize("world,root,W,H,nviews,strip", [(2, 0, 16, 40, 1, 8), (3, 1, 7, 100, 2, 16), (8, 0, 6, 4320 // 10, 2, 64), (5, 4, 3, 9, 1, 8), (4, 2, 5, 64, 3, 64)])
+def test_strip_partition_and_its_gather_plan(world, root, W, H, nviews, strip):
+    """Interleaved strips: every row belongs to exactly one rank, strip s to rank s %% world, and the plan's byte moves rebuild every
+    frame on the root from band buffers that hold each rank's strips of a view back to back."""
+    owner = np.full(H, -1)
+    for r in range(world):
+        segs = mirt.partition_segments(r, world, H, strip)
+        assert all(a % strip == 0 and (a // strip) % world == r and b == min(a + strip, H) for a, b in segs)
+        for a, b in segs:
+            assert (owner[a:b] == -1).all()
+            owner[a:b] = r
+    assert (owner >= 0).all()
+    rng = np.random.RandomState(world * 1000 + H)
+    full = rng.randint(0, 2 ** 32, (nviews, H, W), dtype=np.uint64).astype(np.uint32)
+    bands = {r: np.concatenate([np.concatenate([full[v, a:b] for a, b in mirt.partition_segments(r, world, H, strip)] or [np.zeros((0, W), np.uint32)])
+                                for v in range(nviews)]).view(np.uint8).reshape(-1) for r in range(world)}
+    frames = np.zeros((nviews, H, W), np.uint32)
+    for a, b in mirt.partition_segments(root, world, H, strip):
+        frames[:, a:b] = full[:, a:b]
+    flat = frames.view(np.uint8).reshape(-1)
+    plan = mirt.partition_plan(world, root, W, H, nviews, strip)
+    assert all(p[3] != root for p in plan)
+    for ro, bo, nbytes, peer in plan:
+        flat[ro:ro + nbytes] = bands[peer][bo:bo + nbytes]
+    assert np.array_equal(frames, full)
+    # strip_rows == 0 is the band partition
+    assert mirt.partition_plan(world, root, W, H, nviews, 0) == mirt.band_plan(world, root, W, H, nviews)
+    assert [s for r in range(world) for s in mirt.partition_segments(r, world, H, 0)] == [b for b in (mirt.band_of(r, world, H) for r in range(world)) if b[1] > b[0]]
+
+
 def test_cpp_world_size_2_partition_and_assembly(tmp_path):
     """tests/cpp/band_plan_test.cpp: one process per rank, bands through pipes in plan order, every word checked."""
     exe = str(tmp_path / "band_plan_test")
@@ -70,7 +100,7 @@ import mirt
 from devbuf import DeviceArray
 rank, world, root = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 idfile = sys.argv[4]
-mirt.init(0)
+mirt.init(rank if os.environ.get("MIRT_TEST_DEVICE_PER_RANK") == "1" else 0)
 if rank == 0:
     cid = mirt.comm_create_id()
     with open(idfile + ".tmp", "wb") as f: f.write(cid)
@@ -80,10 +110,15 @@ else:
     while not os.path.exists(idfile): time.sleep(0.01)
     cid = open(idfile, "rb").read()
 mirt.comm_init(cid, rank, world)
+strip = int(os.environ.get("MIRT_TEST_STRIP_ROWS", "0"))
+mirt.set_partition(strip)
+own = np.zeros(131, bool)
 L = np.array([[0.0, -0.5, -0.7, 1, 1, 1, 14]], np.float32)
 W, H = 200, 131
 ok = True
-for kind, scene in (("rt", "cornell"), ("rt", "soup"), ("raster", "cornell")):
+# (the last one: a ray-traced batch right after a rasterised one of the same size -- the band buffers then hold rasterised
+# pixels where the ray tracer writes nothing, the 1-pixel border, and those words must still travel as 0)
+for kind, scene in (("rt", "cornell"), ("rt", "soup"), ("raster", "cornell"), ("rt", "cornell")):
     tris = mirt.scene_cornell() if scene == "cornell" else np.concatenate([mirt.scene_cornell(), mirt.scene_soup(4, 3000, 0.1)])
     views = [mirt.make_view((0.05 * i, 0, -2.6), mirt.rot_from_yaw(0.1 * i, 1.01 if kind == "raster" else 1.0), 70.0, W, H) for i in range(3)]
     mirt.scene_upload(tris, mirt.cull(tris, views[0], 0) if kind == "raster" else None)
@@ -102,8 +137,14 @@ for kind, scene in (("rt", "cornell"), ("rt", "soup"), ("raster", "cornell")):
                 mirt.rasterise_device(v, L, (0.2, 0.2, 0.2), 0, H, 0, ref.ptr, W * 4)
             want = ref.read()
             if kind == "rt":
-                # border words: the ray tracer never writes them; received bands carry 0 there, the root's own band the fill
-                want[0, :] = got[i][0, :]; want[-1, :] = got[i][-1, :]; want[:, 0] = got[i][:, 0]; want[:, -1] = got[i][:, -1]
+                # border words: the ray tracer never writes them -- the root's own rows keep the caller's fill, received bands carry 0
+                border = np.zeros((H, W), bool)
+                border[0, :] = border[-1, :] = True; border[:, 0] = border[:, -1] = True
+                own = np.zeros((H, W), bool)
+                for ry0, ry1 in mirt.partition_segments(root, world, H, strip):
+                    own[ry0:ry1] = True
+                want[border & own] = 0x33333333
+                want[border & ~own] = 0
             if not np.array_equal(got[i], want):
                 ok = False
                 print("MISMATCH", kind, scene, "view", i, int((got[i] != want).sum()), flush=True)
@@ -116,10 +157,10 @@ sys.exit(0 if ok else 1)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,root", [(2, 0), (3, 1)])
-def test_sharded_frames_through_the_loopback_transport(tmp_path, world, root):
+@pytest.mark.parametrize("world,root,strip", [(2, 0, 0), (3, 1, 0), (2, 1, 16), (3, 0, 8)])
+def test_sharded_frames_through_the_loopback_transport(tmp_path, world, root, strip):
     code = RANK_CODE % {"pkg": os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), "tests": os.path.join(ROOT, "tests")}
-    env = dict(os.environ, MIRT_COMM="shm")
+    env = dict(os.environ, MIRT_COMM="shm", MIRT_TEST_STRIP_ROWS=str(strip))
     idfile = str(tmp_path / "comm_id")
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(root), idfile], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
@@ -182,6 +223,32 @@ if dist is not None:
     dist.destroy_process_group()
 print("selfcheck ok", flush=True)
 """
+
+
+@pytest.mark.gpu
+def test_sharded_frames_over_rccl_on_two_devices(tmp_path):
+    """The same frames with one rank per DEVICE and the library's RCCL transport (grouped ncclSend / ncclRecv over xGMI): the
+    multi-GPU path as bench.py --gpus N runs it.  Needs two GPUs; skipped on a one-GPU box (where the loopback transport and the
+    group of one rank above are what can run)."""
+    import torch
+    if torch.cuda.device_count() < 2:                  # (counting devices does not initialise the GPU in this process)
+        pytest.skip("needs two GPUs")
+    code = RANK_CODE % {"pkg": os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), "tests": os.path.join(ROOT, "tests")}
+    env = {k: v for k, v in os.environ.items() if k != "MIRT_COMM"}
+    env["MIRT_TEST_DEVICE_PER_RANK"] = "1"
+    idfile = str(tmp_path / "comm_id")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", "0", idfile], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
 
 @pytest.mark.gpu

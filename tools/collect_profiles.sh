@@ -8,11 +8,12 @@
 set -uo pipefail
 stage="${1:-pmc}"
 if [ "$stage" = pmc ]; then
-  for t in cornell1080 soup100k raster4k; do
-    tools/prof.sh $t --workload $t --steps 20 --warmup 3 > /dev/null 2>&1; echo "trace $t rc=$?"
-    tools/pmc_hbm.sh $t --workload $t --steps 10 --warmup 2 > /dev/null 2>&1
+  for t in soup100k cornell1080 raster4k soup1m8k; do
+    steps=20; [ $t = soup1m8k ] && steps=4
+    tools/prof.sh $t --workload $t --steps $steps --warmup 3 > /dev/null 2>&1; echo "trace $t rc=$?"
+    tools/pmc_hbm.sh $t --workload $t --steps $((steps / 2)) --warmup 2 > /dev/null 2>&1
     python tools/pmc_summary.py gpurun_out/pmc_$t > gpurun_out/pmc_$t/summary.json
-    tools/pmc_valu.sh $t --workload $t --steps 10 --warmup 2 > gpurun_out/pmcv_$t.txt 2>&1
+    tools/pmc_valu.sh $t --workload $t --steps $((steps / 2)) --warmup 2 > gpurun_out/pmcv_$t.txt 2>&1
     python tools/pmc_issue_summary.py gpurun_out/pmcv_$t > gpurun_out/pmcv_$t/summary.json; echo "pmc $t rc=$?"
     # the per-dispatch tables are tens of MiB per pass (gpurun merges at most 64 MiB back): the summaries are what is kept
     find gpurun_out/prof_$t gpurun_out/pmc_$t gpurun_out/pmcv_$t -name "*counter_collection.csv" -delete -o -name "*kernel_trace.csv" -delete
@@ -26,7 +27,7 @@ if [ "$stage" = pmc ]; then
   python tools/fuzz_raster_sequence.py 0 40 > gpurun_out/fuzz_raster_call_sequences.txt 2>&1; echo "fuzz raster sequences rc=$?"
 else
   python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench default rc=$?"
-  for w in cornell1080 soup100k raster4k cornell500 cornell1080soft16 cornell1080aa3 cornell1080dof8 raster4kdof8; do
+  for w in soup100k cornell1080 raster4k cornell500 cornell1080soft16 cornell1080aa3 cornell1080dof8 raster4kdof8; do
     python bench.py --workload $w > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err; echo "bench $w rc=$?"
   done
   python bench.py --workload soup1m8k --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_soup1m8k.json 2>/dev/null; echo "bench soup1m8k rc=$?"

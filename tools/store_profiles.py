@@ -5,18 +5,20 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest               # noqa: E402  (the stamp bench.py checks before it trusts a counter read from a file)
 for f in glob.glob("gpurun_out/bench_*.json"):
     if os.path.getsize(f) > 0:
         shutil.copy(f, "profiles/%s_%s" % (tag, os.path.basename(f)))
 traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_hbm.sh: FETCH_SIZE and WRITE_SIZE in separate passes, "
                        "KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM); summarised by tools/pmc_summary.py (every "
-                       "kernel of the run). MI355X, bench.py defaults (moving camera, two frames in flight).",
-           "workloads": {}}
+                       "kernel of the run). MI355X, bench.py defaults (moving camera, frames in flight).",
+           "csrc_sha16": csrc_digest(), "workloads": {}}
 issue = {"_comment": "issue-side PMC counters per launch (tools/pmc_valu.sh: two rocprofv3 --pmc passes, kernel-trace only), averaged "
                      "over the launches by tools/pmc_issue_summary.py. MI355X, bench.py defaults.",
-         "workloads": {}}
-for t in ("cornell1080", "soup100k", "raster4k"):
+         "csrc_sha16": csrc_digest(), "workloads": {}}
+for t in ("cornell1080", "soup100k", "raster4k", "soup1m8k"):
     stats = sorted(glob.glob("gpurun_out/prof_%s/trace/*/*_kernel_stats.csv" % t), key=os.path.getmtime)
     if stats:
         shutil.copy(stats[-1], "profiles/%s_rocprof_%s_kernel_stats.csv" % (tag, t))
