@@ -303,7 +303,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     # One GPU: several frames in flight, each into its own band buffer (the library takes its streams in turn, so the next
     # frames are dispatched -- and fill the device's gaps -- while the previous ones drain).  Several GPUs: one frame in
     # flight per rank, the RCCL gather of the previous batch overlaps it instead.
-    in_flight = int(os.environ.get("MIRT_BENCH_IN_FLIGHT", "3")) if world == 1 else 1
+    in_flight = int(os.environ.get("MIRT_BENCH_IN_FLIGHT", "4")) if world == 1 else 1
     depth = max(2, in_flight)
     # Several GPUs: frames that render faster than a collective starts (the 30-triangle scenes) travel `batch` at a time --
     # one RCCL gather moves the bands of 32 consecutive frames; heavy frames (the soups: milliseconds) go one per gather.
@@ -638,6 +638,20 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                      "traffic": measured_traffic(name, [""]) if world == 1 else None,
                                      "algorithmic_bytes": int(algo_bytes),
                                      "kernel_ms_sum": round(sum(kernel_ms.get(k, 0.0) for k in ("clear", "raster_setup", "raster_frag", "raster_resolve")), 5)}
+        if dof and kernel_ms.get("dof", 0.0) > 0:
+            # the depth-of-field pass: K*K taps x 3 channels x (multiply, add) per pixel, two per packed
+            # instruction -- VALU-bound; its issue fraction from the committed PMC pass of this workload
+            kd = kernel_ms["dof"]
+            floor_insts = W * (y1 - y0) * dof * dof * 3.0 / 64.0          # packed wave-instructions per launch at two operations each
+            dinsts = measured_valu_instructions(name, "k_dof_tile") if world == 1 else None
+            out["dof"] = {"kernel": "k_dof_tile<%d>" % dof, "kernel_ms": round(kd, 5),
+                          "kernel_ms_alone": round(kernel_ms_alone["dof"], 5) if kernel_ms_alone and kernel_ms_alone.get("dof") else None,
+                          "packed_instruction_floor_per_launch": int(floor_insts),
+                          "floor_ms_at_issue_ceiling": round(floor_insts / (ISSUE_CEILING * 2.4e9 * 1024) * 1e3, 5),
+                          "valu_issue": None if not dinsts else {"instructions_per_launch": int(dinsts), "achieved": round(dinsts / (kd * 1e-3 * 2.4e9 * 1024), 4),
+                                                                 "peak": ISSUE_CEILING, "unit": "wave-instr/clk/SIMD",
+                                                                 "frac": round(dinsts / (kd * 1e-3 * 2.4e9 * 1024) / ISSUE_CEILING, 4),
+                                                                 "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}}
         if world == 1 and want_cpu:
             # deferred (main() runs it after every GPU measurement of the line): tens of seconds of host-only work let the GPU
             # drop its clocks, and the workload timed next would start on a cold device

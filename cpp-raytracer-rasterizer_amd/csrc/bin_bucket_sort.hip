@@ -22,9 +22,11 @@
 
 namespace mirt {
 
-constexpr int BS_PER_THREAD = 16;
+constexpr int BS_PER_THREAD = 16;                // pairs per thread and chunk of k_bs_scatter (8 / 4: the 100 k soup's binning chain 68 / 75 us against 65)
 constexpr int BS_CHUNK = 256 * BS_PER_THREAD;
 constexpr int BS_LOCAL_PER_THREAD = 16;
+constexpr int BS_MAX_SHIFT = 12;
+constexpr int BS_MAX_BUCKET_KEYS = 1 << BS_MAX_SHIFT;    // keys of the largest bucket: one LDS counter each in k_bs_local (16 KiB)
 
 // exclusive scan of v over the 256 threads of the workgroup; *total = sum
 __device__ __forceinline__ uint32_t bs_block_scan(uint32_t v, uint32_t *s_wave /* 4 */, uint32_t *total)
@@ -101,14 +103,14 @@ __global__ __launch_bounds__(256) void k_bs_scatter(const uint32_t *__restrict__
     }
 }
 
-// One workgroup per bucket of (1 << shift) <= 1024 bins.  Leaves bucket_cnt[bucket] = cursor[bucket] = 0 for the next sort.
+// One workgroup per bucket of (1 << shift) <= BS_MAX_BUCKET_KEYS keys.  Leaves bucket_cnt[bucket] = cursor[bucket] = 0 for the next sort.
 __global__ __launch_bounds__(256) void k_bs_local(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                   const uint32_t *__restrict__ total_ptr, uint32_t cap,
                                                   const uint32_t *__restrict__ bucket_base, uint32_t nbins, int shift,
                                                   uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ cursor,
                                                   uint32_t *__restrict__ bin_off, uint32_t *__restrict__ entries)
 {
-    __shared__ uint32_t s_cnt[1024], s_wave[4];
+    __shared__ uint32_t s_cnt[BS_MAX_BUCKET_KEYS], s_wave[4];
     const uint32_t bucket = blockIdx.x;
     if (threadIdx.x == 0) { bucket_cnt[bucket] = 0u; cursor[bucket] = 0u; }
     if (*total_ptr > cap) return;                        // overflowed list (see k_bs_scatter): only the counters are reset
@@ -159,14 +161,16 @@ __global__ __launch_bounds__(256) void k_bs_local(const uint32_t *__restrict__ k
     }
 }
 
-// bins per bucket = 1 << shift: 256 (measured on the 0.5 M pairs of the 100 k soup's camera frame: scatter + local take 57 /
-// 38 / 28 / 25 us at 32 / 64 / 128 / 256 bins per bucket -- fewer buckets mean longer contiguous runs in the scatter's
-// output), more where that many buckets would not fit the LDS counters (8192); more than 8192 buckets of 1024 bins is beyond
-// this sort.
+// keys per bucket = 1 << shift: 256 (measured on the 0.5 M pairs of the 100 k soup's camera frame: scatter + local take 57 /
+// 38 / 28 / 25 us at 32 / 64 / 128 / 256 keys per bucket -- fewer buckets mean longer contiguous runs in the scatter's
+// output), more -- up to 4096, one LDS counter each in k_bs_local -- where that many buckets would be more than ~1000: every
+// flush of k_bin_pairs adds its pairs-per-bucket histogram to the global counts with one atomic per bucket it touched, and the
+// pairs of a chunk of a triangle soup touch them all (1 M triangles at 8K, 4.1 M keys: 4050 buckets of 1024 keys made
+// k_bin_pairs 2.1 ms of a 1.3 ms frame's GPU time; 1013 buckets of 4096: see DESIGN.md section 5).
 int bucket_sort_shift(uint32_t nbins)
 {
     int shift = 8;
-    while (shift < 10 && ((nbins + 1u + (1u << shift) - 1u) >> shift) > 8192u) shift++;
+    while (shift < BS_MAX_SHIFT && ((nbins + 1u + (1u << shift) - 1u) >> shift) > 1024u) shift++;
     // few bins (the 64 x 64 light cube of a moving light: 24 576): smaller buckets, so that k_bs_local has a workgroup per CU
     // and no bucket holds tens of thousands of pairs (one workgroup places a bucket's pairs: 63 -> 20 us on the 100 k soup)
     while (shift > 4 && ((nbins + 1u + (1u << shift) - 1u) >> shift) < 512u) shift--;

@@ -56,13 +56,13 @@ __device__ __forceinline__ void dof_fence2(f2 *fxy, f2 *fz, const float *row)
 
 // One tile row: z = zlo + (RR - p) for output p.  Everything that depends on (RR, c, p) is resolved at compile time.
 // fxy: (r, g) of each output; fz: b of outputs (2q, 2q+1); wo2: their off-centre weights; cur: the K taps of the
-// current tile row as they lie in memory.
+// current tile row as they lie in memory; nxt: where the next row's taps are read to (the two register sets swap roles
+// from row to row: copying next into current cost 24 moves per row, a sixth of the kernel's instructions).
 template <int RR, int KT>
 __device__ __forceinline__ void dof_row(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2], const f2 (&wo2)[DOF_PY / 2], const float (&wc)[DOF_PY],
-                                        const float (&wo)[DOF_PY], float (&cur)[3 * KT], const float *t0, int pitch)
+                                        const float (&wo)[DOF_PY], float (&cur)[3 * KT], float (&nxt)[3 * KT], const float *t0, int pitch)
 {
     constexpr int ZC = KT / 2;                        // -ceil(KT / -2.0f): index of the centre tap
-    float nxt[3 * KT];
     if constexpr (RR + 1 < DOF_PY + KT - 1) {
         // the reads of row RR+1 are issued (volatile: they stay where they are written) before the arithmetic of row RR
         typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
@@ -98,18 +98,14 @@ __device__ __forceinline__ void dof_row(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2],
         }
     }
     dof_fence2(fxy, fz, t0);
-    if constexpr (RR + 1 < DOF_PY + KT - 1) {
-#pragma unroll
-        for (int i = 0; i < 3 * KT; i++) cur[i] = nxt[i];
-    }
 }
 
 template <int KT, int... RR>
 __device__ __forceinline__ void dof_rows(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2], const f2 (&wo2)[DOF_PY / 2], const float (&wc)[DOF_PY],
-                                         const float (&wo)[DOF_PY], float (&cur)[3 * KT], const float *t0, int pitch,
+                                         const float (&wo)[DOF_PY], float (&even)[3 * KT], float (&odd)[3 * KT], const float *t0, int pitch,
                                          std::integer_sequence<int, RR...>)
 {
-    (dof_row<RR, KT>(fxy, fz, wo2, wc, wo, cur, t0, pitch), ...);
+    (dof_row<RR, KT>(fxy, fz, wo2, wc, wo, (RR & 1) ? odd : even, (RR & 1) ? even : odd, t0, pitch), ...);
 }
 
 // One pixelColours element by flat index, 0 outside the frame or outside the rows this call rendered.
@@ -201,10 +197,10 @@ __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame 
         for (int p = 0; p < DOF_PY; p++) fxy[p] = (f2){ 0.0f, 0.0f };
 #pragma unroll
         for (int q = 0; q < DOF_PY / 2; q++) { fz[q] = (f2){ 0.0f, 0.0f }; wo2[q] = (f2){ wo[2 * q], wo[2 * q + 1] }; }
-        float cur[3 * KT];
+        float even[3 * KT], odd[3 * KT];                  // the taps of even / odd tile rows
 #pragma unroll
-        for (int i = 0; i < 3 * KT; i++) cur[i] = t0[i];
-        dof_rows<KT>(fxy, fz, wo2, wc, wo, cur, t0, pitch, std::make_integer_sequence<int, DOF_PY + KT - 1>());
+        for (int i = 0; i < 3 * KT; i++) even[i] = t0[i];
+        dof_rows<KT>(fxy, fz, wo2, wc, wo, even, odd, t0, pitch, std::make_integer_sequence<int, DOF_PY + KT - 1>());
 #pragma unroll
         for (int p = 0; p < DOF_PY; p++) fin[p] = V3(fxy[p].x, fxy[p].y, (p & 1) ? fz[p / 2].y : fz[p / 2].x);
     } else {

@@ -826,7 +826,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         if ((rc = dev_realloc(&S.d_order, (size_t)ORDER_CLASSES * npairs))) return rc;
         S.cap_order = npairs;
     }
-    hipLaunchKernelGGL(k_tile_order, dim3((npairs + 255) / 256), dim3(256), 0, g.stream, S.d_bin_off, bs.frame0.nshell, bs.frame0.nbu,
+    hipLaunchKernelGGL(k_tile_order, dim3((npairs + 1023) / 1024), dim3(1024), 0, g.stream, S.d_bin_off, bs.frame0.nshell, bs.frame0.nbu,
                        bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order);
     k_end(MIRT_K_BIN);
 

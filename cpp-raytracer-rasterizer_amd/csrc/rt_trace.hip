@@ -252,7 +252,7 @@ struct RtTraceFrame {
 // classic greedy schedule.  A record carries the pair's list bounds, so the wave's first load is its last indirection.
 // counters: [0] = pairs the binning pass produced (> pair_cap: the lists are incomplete, the frame is brute force and every
 // record goes to class 0), [16 + c] = records in class c (zeroed by k_prep_origin).
-__global__ __launch_bounds__(256) void k_tile_order(const uint32_t *__restrict__ cam_off, int cam_shells, int tiles_x, int j0, int j1,
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t *__restrict__ cam_off, int cam_shells, int tiles_x, int j0, int j1,
                                                     uint32_t *__restrict__ counters, uint32_t pair_cap, TilePairRec *__restrict__ order)
 {
     const int pairs_x = (tiles_x + 1) / 2, npairs = pairs_x * (j1 - j0);
@@ -270,8 +270,13 @@ __global__ __launch_bounds__(256) void k_tile_order(const uint32_t *__restrict__
             cls = (int)min(max(r.nA, r.nB) / ORDER_CLASS_STEP, (uint32_t)(ORDER_CLASSES - 1));
         }
     }
-    // ONE atomic instruction per wave: lane c adds the wave's count of class c (a class counter bumped once per record would
-    // serialise ~7 ns apiece; eight dependent atomics in a row made this kernel 13 us of round trips)
+    // ONE global atomic instruction per WORKGROUP: the waves rank their records within the workgroup through LDS counters, lane c
+    // of wave 0 then adds the workgroup's count of class c (a class counter bumped once per record would serialise ~7 ns apiece;
+    // eight dependent atomics in a row made this kernel 13 us of round trips; one atomic per wave still queued 4050 of them on
+    // the emptiest class's counter at 8K: 51 us)
+    __shared__ uint32_t s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
+    if (threadIdx.x < ORDER_CLASSES) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
     unsigned long long m[ORDER_CLASSES];
     uint32_t mine = 0;
 #pragma unroll
@@ -279,11 +284,14 @@ __global__ __launch_bounds__(256) void k_tile_order(const uint32_t *__restrict__
         m[c] = __builtin_amdgcn_ballot_w64(cls == c);
         if (lane == c) mine = (uint32_t)__popcll(m[c]);
     }
-    uint32_t base = 0;
-    if (lane < ORDER_CLASSES && mine) base = atomicAdd(&counters[16 + lane], mine);
+    uint32_t wbase = 0;                                    // where this wave's records of class `lane` start within the workgroup's
+    if (lane < ORDER_CLASSES && mine) wbase = atomicAdd(&s_cnt[lane], mine);
+    __syncthreads();
+    if (threadIdx.x < ORDER_CLASSES) { const uint32_t c = s_cnt[threadIdx.x]; s_base[threadIdx.x] = c ? atomicAdd(&counters[16 + threadIdx.x], c) : 0u; }
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < ORDER_CLASSES; c++) {
-        const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)base, c);
+        const uint32_t bc = s_base[c] + (uint32_t)__builtin_amdgcn_readlane((int)wbase, c);
         if (cls == c) order[(size_t)c * npairs + bc + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
     }
 }

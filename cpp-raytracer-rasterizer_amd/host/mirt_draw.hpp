@@ -171,6 +171,7 @@ struct Rasteriser {
     Surface screen = { nullptr, 0, 0, 0 };
     bool isUpdated = true;
     bool scene_dirty = true;
+    bool culled_dirty = true;                        // host-side cull flags changed since the last upload (Update())
     std::vector<float> packed;                        // 15-float view of `triangles` for the ABI
     std::vector<uint8_t> culled;
 
@@ -221,6 +222,7 @@ struct Rasteriser {
             check(mirt_cull(packed.data(), (int)triangles.size(), &view, flags, culled.data()), "mirt_cull");
         }
         for (size_t i = 0; i < triangles.size(); i++) triangles[i].isCulled = culled[i] != 0;   // :406,412,445
+        culled_dirty = !GPU_CULL;                     // host-side flags: the device copy is stale until the next Draw() uploads them
     }
     void Draw()
     {
@@ -243,8 +245,13 @@ private:
         if (scene_dirty) {
             check(mirt_scene_upload(packed.data(), culled.data(), (int)triangles.size()), "mirt_scene_upload");
             scene_dirty = false;
-        } else if (!GPU_CULL) {                       // with GPU_CULL the flags are already on the device
+            culled_dirty = false;
+        } else if (culled_dirty) {
+            // Host-side cull flags travel only when Update() changed them: the upload waits for every frame in flight
+            // (mirt_scene_set_culled), so a loop that draws several frames per Update() keeps its overlap.  With GPU_CULL the
+            // flags are already on the device and nothing is uploaded at all -- the mode DrawAsync is meant for.
             check(mirt_scene_set_culled(culled.data(), (int)culled.size()), "mirt_scene_set_culled");
+            culled_dirty = false;
         }
         check(mirt_set_depth_of_field(DOF_ENABLED ? DOF_KERNEL_SIZE : 0, FOCAL_LENGTH), "mirt_set_depth_of_field");   // CalculateDOF (:484-529)
         return make_view(cameraPos, cameraRot, focalLength, SCREEN_WIDTH, SCREEN_HEIGHT);

@@ -8,7 +8,7 @@
 set -uo pipefail
 stage="${1:-pmc}"
 if [ "$stage" = pmc ]; then
-  for t in soup100k cornell1080 raster4k soup1m8k; do
+  for t in soup100k cornell1080 raster4k soup1m8k raster4kdof8; do
     steps=20; [ $t = soup1m8k ] && steps=4
     tools/prof.sh $t --workload $t --steps $steps --warmup 3 > /dev/null 2>&1; echo "trace $t rc=$?"
     tools/pmc_hbm.sh $t --workload $t --steps $((steps / 2)) --warmup 2 > /dev/null 2>&1

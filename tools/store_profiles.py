@@ -18,7 +18,7 @@ traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (tools/pm
 issue = {"_comment": "issue-side PMC counters per launch (tools/pmc_valu.sh: two rocprofv3 --pmc passes, kernel-trace only), averaged "
                      "over the launches by tools/pmc_issue_summary.py. MI355X, bench.py defaults.",
          "csrc_sha16": csrc_digest(), "workloads": {}}
-for t in ("cornell1080", "soup100k", "raster4k", "soup1m8k"):
+for t in ("cornell1080", "soup100k", "raster4k", "soup1m8k", "raster4kdof8"):
     stats = sorted(glob.glob("gpurun_out/prof_%s/trace/*/*_kernel_stats.csv" % t), key=os.path.getmtime)
     if stats:
         shutil.copy(stats[-1], "profiles/%s_rocprof_%s_kernel_stats.csv" % (tag, t))

@@ -11,11 +11,12 @@ sys.path[:0] = [os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), os.path.join
 import mirt                                 # noqa: E402
 from devbuf import DeviceArray              # noqa: E402
 
-W, H = 1920, 1080
+big = "1m8k" in sys.argv                    # BASELINE config 5 (1 M triangles, 8K) instead of config 3 (100 k, 1080p)
+W, H = (7680, 4320) if big else (1920, 1080)
 lights = np.zeros((0, 7), np.float32) if "nolight" in sys.argv else np.array([[0.0, -0.5, -0.7, 1, 1, 1, 14]], np.float32)
 mirt.init(0)
-mirt.scene_upload(mirt.scene_soup(1, 100000, 0.05))
-view = mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.0, 1.0), 540.0, W, H)
+mirt.scene_upload(mirt.scene_soup(2, 1000000, 0.02) if big else mirt.scene_soup(1, 100000, 0.05))
+view = mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.0, 1.0), H / 2.0, W, H)
 x = DeviceArray((H, W), np.uint32)
 for it in range(12):
     mirt.raytrace_device(view, lights, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, x.ptr, W * 4)
