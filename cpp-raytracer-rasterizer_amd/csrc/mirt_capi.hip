@@ -37,7 +37,7 @@ __global__ void k_tile_tables(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile2(const RtTileFrame);
 __global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
 struct TilePairRec { uint32_t tile, beg, nA, nB; };
-constexpr int ORDER_CLASSES = 8;
+constexpr int ORDER_CLASSES = 8, ORDER_GROUPS = 8;
 struct RtTraceFrame {                            // (rt_trace.hip)
     RtFrame f;
     const uint32_t *cam_off;
@@ -56,10 +56,10 @@ struct RtTraceFrame {                            // (rt_trace.hip)
     uint32_t pair_cap;
     const TilePairRec *order;
     const uint32_t *order_count;
-    uint32_t npairs;
+    uint32_t order_seg;
 };
 template <bool AA> __global__ void k_rt_trace2(const RtTraceFrame);
-__global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *);
+__global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *, uint32_t);
 __global__ void k_geo_table(const float *, int, GeoRow *, ShadeRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t,
                                     const float *, const float *, uint32_t *);
@@ -637,7 +637,7 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
     }
     if (!C.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_frames), sizeof(BinFrameDesc) * 6 * MIRT_MAX_LIGHTS));
     if (!C.d_origins) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_origins), sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
-    if (!C.d_counter) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_counter), 64)); HIP_TRY(hipMemsetAsync(C.d_counter, 0, 64, g.stream)); }   // (ON the stream: see zero-fill note at S.d_bin_counters)
+    if (!C.d_counter) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&C.d_counter), 512)); HIP_TRY(hipMemsetAsync(C.d_counter, 0, 512, g.stream)); }   // (k_prep_origin zeroes words 0 and 16..79 of a pass's counter block)   // (ON the stream: see zero-fill note at S.d_bin_counters)
     C.nbins = nkeys;
     C.nrows = 0;
     C.shells = shells;
@@ -761,7 +761,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     // are not ordered with -- with several processes on one device (three ranks rehearsing a sharded run) such a fill has been seen
     // to land AFTER the first kernels of g.stream had started counting, which cut the pair count short (a light cube built from
     // it kept wrong shadows until the lights moved; a camera pass failed with "produced N pairs twice").
-    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 128)); HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 128, g.stream)); }
+    if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 512)); HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 512, g.stream)); }
     bs.bin_off = S.d_bin_off;
 
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
@@ -818,16 +818,20 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
                            S.d_bin_off + light_key0, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used,
                            g.d_tris, S.d_origins, (uint32_t *)nullptr);
     }
-    // the order the trace kernel's waves take the tile pairs in: longest lists first
-    const uint32_t npairs = (uint32_t)((bs.frame0.nbu + 1) / 2) * (uint32_t)(bs.frame0.j1 - bs.frame0.j0);
-    if (npairs > S.cap_order) {
+    // the order the trace kernel's waves take the tile pairs in: per XCD group (pairs of tile rows dealt round-robin), longest
+    // lists first
+    const uint32_t pairs_x = (uint32_t)((bs.frame0.nbu + 1) / 2);
+    uint32_t group_rows[ORDER_GROUPS] = { 0 };
+    for (int j = bs.frame0.j0; j < bs.frame0.j1; j++) group_rows[((uint32_t)j >> ORDER_STRIPE_SHIFT) & (ORDER_GROUPS - 1)]++;
+    const uint32_t order_seg = pairs_x * *std::max_element(group_rows, group_rows + ORDER_GROUPS);
+    if ((size_t)order_seg > S.cap_order) {
         HIP_TRY(hipStreamSynchronize(g.stream));
         S.cap_order = 0;
-        if ((rc = dev_realloc(&S.d_order, (size_t)ORDER_CLASSES * npairs))) return rc;
-        S.cap_order = npairs;
+        if ((rc = dev_realloc(&S.d_order, (size_t)ORDER_GROUPS * ORDER_CLASSES * order_seg))) return rc;
+        S.cap_order = order_seg;
     }
-    hipLaunchKernelGGL(k_tile_order, dim3((npairs + 1023) / 1024), dim3(1024), 0, g.stream, S.d_bin_off, bs.frame0.nshell, bs.frame0.nbu,
-                       bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order);
+    hipLaunchKernelGGL(k_tile_order, dim3((pairs_x + 63) / 64, (unsigned)(bs.frame0.j1 - bs.frame0.j0)), dim3(64), 0, g.stream, S.d_bin_off, bs.frame0.nshell,
+                       bs.frame0.nbu, bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order, order_seg);
     k_end(MIRT_K_BIN);
 
     RtTraceFrame tf;
@@ -852,9 +856,9 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.pair_count = S.d_bin_counters;
     tf.pair_cap = S.cap_used;
     // one wave per pair of 8 x 8 tiles
-    tf.order = S.d_order; tf.order_count = S.d_bin_counters + 16; tf.npairs = npairs;
+    tf.order = S.d_order; tf.order_count = S.d_bin_counters + 16; tf.order_seg = order_seg;
     // (waves never synchronise with each other: one-wave workgroups are the finest scheduling unit; 84 / 87 / 89 us with 1 / 2 / 4)
-    const dim3 tgrid(npairs);
+    const dim3 tgrid(ORDER_GROUPS * order_seg);             // (workgroup id % 8 = XCD group, id / 8 = the wave among the group's)
     const size_t lds = rt_trace_lds_bytes(1);
     k_begin(MIRT_K_TRACE);
     if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace2<true>, tgrid, dim3(64), lds, g.stream, tf);

@@ -26,6 +26,10 @@
 
 namespace mirt {
 
+#ifndef MIRT_ORDER_STRIPE_SHIFT
+#define MIRT_ORDER_STRIPE_SHIFT 2
+#endif
+constexpr int ORDER_STRIPE_SHIFT = MIRT_ORDER_STRIPE_SHIFT;   // log2 of the tile rows per stripe dealt to one XCD group (rt_trace.hip: k_tile_order)
 constexpr int BIN_TILE = 8;            // camera bins are 8x8 pixels = one wave64
 constexpr int BIN_COARSE = 8;          // coarse cell = 8x8 fine bins (the three-level walk of huge items, rt_binned.hip)
 constexpr int BIN_WG = 512;            // threads of a k_bin_pairs workgroup: a work item's 256 triangles are set up by the first four waves, the

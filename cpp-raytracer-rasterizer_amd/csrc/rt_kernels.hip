@@ -26,8 +26,9 @@ __global__ __launch_bounds__(256) void k_prep_origin(const float *__restrict__ t
     if (blockIdx.y == 0 && blockIdx.x == 0) {
         if (zero_hits)
             for (int g = threadIdx.x; g < HIT_SHARDS * HIT_SHARD_STRIDE; g += blockDim.x) zero_hits[g] = 0ull;
-        // [0] pairs of the binning pass, [16..23] tile pairs per list-length class (k_tile_order); the words between: debug statistics
-        if (zero_counter && (threadIdx.x == 0 || (threadIdx.x >= 16 && threadIdx.x < 24))) zero_counter[threadIdx.x] = 0u;
+        // [0] pairs of the binning pass, [16..79] tile pairs per (XCD group, list-length class) (k_tile_order); the words between:
+        // debug statistics
+        if (zero_counter && (threadIdx.x == 0 || (threadIdx.x >= 16 && threadIdx.x < 80))) zero_counter[threadIdx.x] = 0u;
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int o = o0 + (int)blockIdx.y;

@@ -221,6 +221,7 @@ __device__ __forceinline__ void cube_bin_of2(const v3p &rd, uint32_t face_base0,
 // follows it), and the two lengths.
 struct TilePairRec { uint32_t tile, beg, nA, nB; };
 constexpr int ORDER_CLASSES = 8;                 // classes of max(nA, nB) / ORDER_CLASS_STEP, the last one open-ended
+constexpr int ORDER_GROUPS = 8;                  // one list per XCD group (workgroup id % 8)
 constexpr uint32_t ORDER_CLASS_STEP = 16;        // = TR_STAGE: a class is a number of staging chunks
 
 struct RtTraceFrame {
@@ -239,28 +240,37 @@ struct RtTraceFrame {
     int light_shells;                 // depth shells per light-cube bin
     const uint32_t *pair_count;       // pairs this frame's binning produced / room in the pair list: beyond it the lists are
     uint32_t pair_cap;                // incomplete and every tile takes the whole triangle list instead (brute force)
-    const TilePairRec *order;         // the frame's tile pairs, longest lists first (k_tile_order): ORDER_CLASSES segments of npairs records
+    const TilePairRec *order;         // the frame's tile pairs by XCD group and list-length class (k_tile_order): ORDER_GROUPS x ORDER_CLASSES
+                                      // segments of order_seg records
     const uint32_t *order_count;      // records in each segment
-    uint32_t npairs;                  // tile pairs of the band = waves that have work
+    uint32_t order_seg;               // room per segment = the most pairs a group can have = waves per group
 };
 
-// One wave renders one PAIR of horizontally adjacent tiles.  Tiles differ a lot in what they cost -- on the 100 k soup 9 % of
-// them hold half of all candidates, ~90 each against an average of 14 -- and a wave that starts such a pair late is what the
-// whole launch then waits for (measured: the longest wave lives 60 us of a launch that would take 58 us with every wave slot
-// always full, and took 85).  k_tile_order therefore files the pairs by the length of their longer list into ORDER_CLASSES
-// classes, and wave w of the trace kernel takes the w-th record counting from the longest class: longest first, the
-// classic greedy schedule.  A record carries the pair's list bounds, so the wave's first load is its last indirection.
-// counters: [0] = pairs the binning pass produced (> pair_cap: the lists are incomplete, the frame is brute force and every
-// record goes to class 0), [16 + c] = records in class c (zeroed by k_prep_origin).
-__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t *__restrict__ cam_off, int cam_shells, int tiles_x, int j0, int j1,
-                                                    uint32_t *__restrict__ counters, uint32_t pair_cap, TilePairRec *__restrict__ order)
+// One wave renders one PAIR of horizontally adjacent tiles.  Two things decide which wave takes which pair:
+//  * Tiles differ a lot in what they cost -- on the 100 k soup 9 % of them hold half of all candidates, ~90 each against an
+//    average of 14 -- and a wave that starts such a pair late is what the whole launch then waits for (measured: the longest wave
+//    lived 60 us of a launch that would take 58 us with every wave slot always full, and took 85).  So pairs are filed by the
+//    length of their longer list into ORDER_CLASSES classes and taken longest class first: the classic greedy schedule.
+//  * Consecutive workgroup ids go to consecutive XCDs, each with an L2 of its own (4 MiB).  With the pairs of the whole frame
+//    in one longest-first list every XCD touched every origin row and geometry row of the frame: 87 MB of fabric reads per
+//    launch for 9.6 MB of tables (L2 hit rate 0.39).  So the frame's pairs of tile rows are dealt to the eight XCD groups in
+//    turn (group = (tile row / 4) % 8, stripes of 32 pixel rows: every group samples the whole height of the frame, so they stay balanced) and each
+//    group has its OWN longest-first list: a triangle of the soup is then wanted by ~2 groups instead of 8, and a group's
+//    share of the tables fits its L2.
+// k_tile_order builds the lists: one wave per 64 pairs of one tile row (so the group is wave-uniform), one global atomic
+// instruction per wave (lane c adds the wave's count of class c to the group's counter).  A record carries the pair's list
+// bounds, so the trace wave's first load is its last indirection.  counters: [0] = pairs the binning pass produced (> pair_cap:
+// the lists are incomplete, the frame is brute force and every record goes to class 0), [16 + 8 * group + c] = records of
+// class c of the group (zeroed by k_prep_origin).
+__global__ __launch_bounds__(64) void k_tile_order(const uint32_t *__restrict__ cam_off, int cam_shells, int tiles_x, int j0, int j1,
+                                                   uint32_t *__restrict__ counters, uint32_t pair_cap, TilePairRec *__restrict__ order, uint32_t seg)
 {
-    const int pairs_x = (tiles_x + 1) / 2, npairs = pairs_x * (j1 - j0);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const int pairs_x = (tiles_x + 1) / 2, lane = threadIdx.x;
+    const int ty = j0 + (int)blockIdx.y, px = (int)blockIdx.x * 64 + lane;
+    const uint32_t group = ((uint32_t)ty >> ORDER_STRIPE_SHIFT) & (ORDER_GROUPS - 1);
     TilePairRec r = { 0u, 0u, 0u, 0u };
     int cls = -1;
-    if (p < npairs) {
-        const int px = p % pairs_x, ty = j0 + p / pairs_x;
+    if (px < pairs_x) {
         r.tile = (uint32_t)(ty * tiles_x + 2 * px);
         cls = 0;
         if (counters[0] <= pair_cap) {
@@ -270,13 +280,6 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t *__restrict_
             cls = (int)min(max(r.nA, r.nB) / ORDER_CLASS_STEP, (uint32_t)(ORDER_CLASSES - 1));
         }
     }
-    // ONE global atomic instruction per WORKGROUP: the waves rank their records within the workgroup through LDS counters, lane c
-    // of wave 0 then adds the workgroup's count of class c (a class counter bumped once per record would serialise ~7 ns apiece;
-    // eight dependent atomics in a row made this kernel 13 us of round trips; one atomic per wave still queued 4050 of them on
-    // the emptiest class's counter at 8K: 51 us)
-    __shared__ uint32_t s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
-    if (threadIdx.x < ORDER_CLASSES) s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
     unsigned long long m[ORDER_CLASSES];
     uint32_t mine = 0;
 #pragma unroll
@@ -284,15 +287,12 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t *__restrict_
         m[c] = __builtin_amdgcn_ballot_w64(cls == c);
         if (lane == c) mine = (uint32_t)__popcll(m[c]);
     }
-    uint32_t wbase = 0;                                    // where this wave's records of class `lane` start within the workgroup's
-    if (lane < ORDER_CLASSES && mine) wbase = atomicAdd(&s_cnt[lane], mine);
-    __syncthreads();
-    if (threadIdx.x < ORDER_CLASSES) { const uint32_t c = s_cnt[threadIdx.x]; s_base[threadIdx.x] = c ? atomicAdd(&counters[16 + threadIdx.x], c) : 0u; }
-    __syncthreads();
+    uint32_t base = 0;
+    if (lane < ORDER_CLASSES && mine) base = atomicAdd(&counters[16 + group * ORDER_CLASSES + lane], mine);
 #pragma unroll
     for (int c = 0; c < ORDER_CLASSES; c++) {
-        const uint32_t bc = s_base[c] + (uint32_t)__builtin_amdgcn_readlane((int)wbase, c);
-        if (cls == c) order[(size_t)c * npairs + bc + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
+        const uint32_t bc = (uint32_t)__builtin_amdgcn_readlane((int)base, c);
+        if (cls == c) order[((size_t)group * ORDER_CLASSES + c) * seg + bc + (uint32_t)__popcll(m[c] & ((1ull << lane) - 1ull))] = r;
     }
 }
 
@@ -312,20 +312,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     TrWaveLds &s = reinterpret_cast<TrWaveLds *>(s_all)[wave];
 
-    // Wave -> tile pair: record w of k_tile_order's list, longest lists first.  (Waves never synchronise with each other, so a
+    // Wave -> tile pair: record w of its XCD group's list (k_tile_order), longest lists first.  (Waves never synchronise with each other, so a
     // workgroup is just a scheduling unit of 1, 2 or 4 of them.)
-    uint32_t w = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
-    if (w >= tf.npairs) return;
+    const uint32_t group = blockIdx.x & (ORDER_GROUPS - 1);                       // = this workgroup's XCD group
+    uint32_t w = (blockIdx.x >> 3) * (blockDim.x >> 6) + (uint32_t)wave;          // this wave among the group's
     TilePairRec rec = { 0u, 0u, 0u, 0u };
     {
         bool found = false;
 #pragma unroll
         for (int c = ORDER_CLASSES - 1; c >= 0; c--) {
-            const uint32_t cnt = tf.order_count[c];
-            if (!found && w < cnt) { rec = tf.order[(size_t)c * tf.npairs + w]; found = true; }
+            const uint32_t cnt = tf.order_count[group * ORDER_CLASSES + c];
+            if (!found && w < cnt) { rec = tf.order[((size_t)group * ORDER_CLASSES + c) * tf.order_seg + w]; found = true; }
             if (!found) w -= cnt;
         }
-        if (!found) return;                                // (cannot happen: the classes hold npairs records)
+        if (!found) return;                                // beyond the group's pairs
     }
     rec.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.tile); rec.beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.beg);
     rec.nA = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.nA); rec.nB = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.nB);

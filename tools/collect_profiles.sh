@@ -1,14 +1,17 @@
 #!/usr/bin/env bash
-# tools/collect_profiles.sh pmc|bench -- (GPU box) every record kept under profiles/ for a round, in two gpurun calls:
-#   pmc    rocprofv3 kernel stats, the HBM-traffic PMC passes and the issue-side PMC passes of the three default workloads,
-#          the microbenchmarks, the binned-vs-brute fuzz and the moving-light run;
+# tools/collect_profiles.sh pmc|fuzz|bench -- (GPU box) every record kept under profiles/ for a round, in three gpurun calls:
+#   pmc    rocprofv3 kernel stats, the HBM-traffic PMC passes and the issue-side PMC passes of the default workloads;
+#   fuzz   the microbenchmarks, the fuzzers and the moving-light run;
 #   bench  the bench lines (with cpu_baseline) -- AFTER `python tools/store_profiles.py <tag>` has put the PMC summaries of
 #          the first call into profiles/, which is where bench.py reads `roofline.traffic` from.
 # Results land in gpurun_out/; tools/store_profiles.py copies the summaries into profiles/ (in the build container).
 set -uo pipefail
 stage="${1:-pmc}"
+shift || true
 if [ "$stage" = pmc ]; then
-  for t in soup100k cornell1080 raster4k soup1m8k raster4kdof8; do
+  # (optionally: tools/collect_profiles.sh pmc <workload> ... -- a gpurun call is at most 20 minutes)
+  [ $# -gt 0 ] || set -- soup100k cornell1080 raster4k soup1m8k raster4kdof8
+  for t in "$@"; do
     steps=20; [ $t = soup1m8k ] && steps=4
     tools/prof.sh $t --workload $t --steps $steps --warmup 3 > /dev/null 2>&1; echo "trace $t rc=$?"
     tools/pmc_hbm.sh $t --workload $t --steps $((steps / 2)) --warmup 2 > /dev/null 2>&1
@@ -18,13 +21,14 @@ if [ "$stage" = pmc ]; then
     # the per-dispatch tables are tens of MiB per pass (gpurun merges at most 64 MiB back): the summaries are what is kept
     find gpurun_out/prof_$t gpurun_out/pmc_$t gpurun_out/pmcv_$t -name "*counter_collection.csv" -delete -o -name "*kernel_trace.csv" -delete
   done
+elif [ "$stage" = fuzz ]; then
   tools/ubench > gpurun_out/ubench.txt 2>&1
   tools/edgebench > gpurun_out/edgebench.txt 2>&1
   python tools/moving_light.py > gpurun_out/moving_light.txt 2>&1; echo "moving light rc=$?"
   python tools/fuzz_binned.py 0 300 6 > gpurun_out/fuzz_binned_vs_brute.txt 2>&1; echo "fuzz rc=$?"
   python tools/fuzz_small.py 0 3000 > gpurun_out/fuzz_small_scenes_vs_oracle.txt 2>&1; echo "fuzz small rc=$?"
-  python tools/fuzz_sequence.py 0 80 > gpurun_out/fuzz_call_sequences.txt 2>&1; echo "fuzz sequences rc=$?"
-  python tools/fuzz_raster_sequence.py 0 40 > gpurun_out/fuzz_raster_call_sequences.txt 2>&1; echo "fuzz raster sequences rc=$?"
+  python tools/fuzz_sequence.py 0 200 > gpurun_out/fuzz_call_sequences.txt 2>&1; echo "fuzz sequences rc=$?"
+  python tools/fuzz_raster_sequence.py 0 200 > gpurun_out/fuzz_raster_call_sequences.txt 2>&1; echo "fuzz raster sequences rc=$?"
 else
   python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "bench default rc=$?"
   for w in soup100k cornell1080 raster4k cornell500 cornell1080soft16 cornell1080aa3 cornell1080dof8 raster4kdof8; do
