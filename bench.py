@@ -41,6 +41,7 @@ import numpy as np  # noqa: E402
 LIGHT = np.array([[0.0, -0.5, -0.7, 1.0, 1.0, 1.0, 14.0]], np.float32)     # raytracer.cpp:116 / rasteriser.cpp:104
 INDIRECT = (0.2, 0.2, 0.2)                                                    # raytracer.cpp:81
 
+RASTER_FLOP_PER_PIXEL = 109.0   # interpolation of the winning fragment + PixelShader with one light, as written (rasteriser.cpp:549-589, 661-662)
 FLOP_PER_TEST = 60.0          # 57 add/mul + 3 div as written in raytracer.cpp:216-239
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: vector FP32 peak (counts FMA as 2; this path may not fuse)
 # what bit-exact parity leaves reachable: no FMA contraction (half the flops per instruction); packed v_pk_* where two rays share
@@ -611,12 +612,57 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                            "width": W, "height": H, "lights": 1, "dof_kernel": dof, "covered_pixels": covered,
                            "parallelism": ("bands%d+%s" % (world, "rccl-p2p-gather(libmirt)" if native else "torch-gather")) if world > 1 else "1gpu"},
             })
-            # Dominant kernel: k_raster_resolve reads the 8-byte depth key of every pixel and writes the XRGB word; it also
-            # re-zeroes the keys it consumed (8 more bytes per COVERED pixel), which replaced the per-frame clear.
             band_px = W * (y1 - y0)
             cov = covered if covered is not None else band_px
             tr = kernel_ms.get("raster_resolve", 0.0)
-            if tr > 0:
+            mode_txt = "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera%s" % (in_flight, "moving" if moving else "static", "; the frame before the last of 6 queued back to back (overlapped on both sides)" if overlapped else "")
+            small = len(tris) <= 64 and os.environ.get("MIRT_RASTER_SMALL", "1") != "0"
+            if small and tr > 0:
+                # Scenes of <= 64 triangles (the reference's Cornell box): k_raster_small keeps the depth test in registers and
+                # writes 4 B per pixel; what it does is the reference's per-pixel arithmetic -- the winning fragment's interpolation
+                # (Bresenham :661-662, 8 flop) and PixelShader (:549-589: 3 divisions by zinv, 15 for the inverse rotation, 3 + 9 + 1
+                # camera / distance / focal, 41 per light incl. 3 divisions and 2 square roots, 9 for the colour, 12 to pack) =
+                # 109 flop per covered pixel with one light, a division or a square root counted as ONE.  VALU-bound, no contraction.
+                flop = RASTER_FLOP_PER_PIXEL * cov
+                ach = flop / (tr * 1e-3) / 1e12
+                out["roofline"] = {"bound": "valu", "kernel": "k_raster_small", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(ach / PEAK_FP32_TFLOPS, 4), "peak_reachable": PEAK_REACHABLE_TFLOPS,
+                                   "frac_of_reachable": round(ach / PEAK_REACHABLE_TFLOPS["no_fma_packed"], 4),
+                                   "primary_fraction": "valu_issue (a division is 11 and a square root 15 instructions on this chip, counted as one flop "
+                                                       "each in `achieved`; issue slots count what the vector pipes do)",
+                                   "traffic": measured_traffic(name, ["k_raster_small"]) if world == 1 else None,
+                                   "traffic_source": "profiles/%s_hbm_traffic.json (rocprofv3 PMC, bytes per launch)" % ROUND,
+                                   "algorithmic_flop": int(flop), "covered_pixels": int(cov), "kernel_ms": round(tr, 5), "kernel_ms_mode": mode_txt,
+                                   "frame": {"achieved": round(flop / (ms_frame * 1e-3) / 1e12, 3), "frac": round(flop / (ms_frame * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                             "ms_per_frame": round(ms_frame, 5)},
+                                   "note": "FP32 VALU-bound: 109 flop per covered pixel as written in the reference (interpolation + PixelShader, one "
+                                           "light), shaded once per pixel for the fragment that wins the depth test"}
+                if kernel_ms_alone and kernel_ms_alone.get("raster_resolve", 0.0) > 0:
+                    ka = kernel_ms_alone["raster_resolve"]
+                    out["roofline"]["alone"] = {"kernel_ms": round(ka, 5), "achieved": round(flop / (ka * 1e-3) / 1e12, 3),
+                                                "frac": round(flop / (ka * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)}
+                insts = measured_valu_instructions(name, "k_raster_small") if world == 1 else None
+                if insts:
+                    ipc = insts / (tr * 1e-3 * 2.4e9 * 1024)
+                    out["roofline"]["valu_issue"] = {"instructions_per_launch": int(insts), "achieved": round(ipc, 4), "peak": ISSUE_CEILING,
+                                                     "unit": "wave-instr/clk/SIMD", "frac": round(ipc / ISSUE_CEILING, 4),
+                                                     "lane_slots_per_pixel": round(insts * 64.0 / band_px, 1),
+                                                     "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}
+                    per_frame = measured_valu_per_frame(name)
+                    if per_frame:
+                        fipc = per_frame / (ms_frame * 1e-3 * 2.4e9 * 1024)
+                        out["roofline"]["valu_issue"]["frame"] = {"instructions_per_frame": int(per_frame), "achieved": round(fipc, 4), "peak": ISSUE_CEILING,
+                                                                  "frac": round(fipc / ISSUE_CEILING, 4), "ms_per_frame": round(ms_frame, 5)}
+                algo_bytes = 4.0 * band_px + 60.0 * len(tris)
+                out["roofline_hbm"] = {"bound": "hbm", "achieved": round(algo_bytes / (tr * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": round(algo_bytes / (tr * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                                       "traffic": measured_traffic(name, ["k_raster_small"]) if world == 1 else None,
+                                       "frame_traffic": measured_traffic(name, ["k_cull", "k_raster"]) if world == 1 else None,
+                                       "algorithmic_bytes": int(algo_bytes),
+                                       "note": "4 B per pixel written + the triangle list; no depth-key buffer on this path"}
+            elif tr > 0:
+                # Larger scenes: k_raster_resolve reads the 8-byte depth key of every pixel and writes the XRGB word; it also
+                # re-zeroes the keys it consumed (8 more bytes per COVERED pixel), which replaced the per-frame clear.
                 rb = 12.0 * band_px + 8.0 * cov
                 out["roofline"] = {"bound": "hbm", "kernel": "k_raster_resolve", "achieved": round(rb / (tr * 1e-3) / 1e9, 3),
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(rb / (tr * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
@@ -627,17 +673,16 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                              {"kernel_ms": round(kernel_ms_alone["raster_resolve"], 5),
                                               "achieved": round(rb / (kernel_ms_alone["raster_resolve"] * 1e-3) / 1e9, 3),
                                               "frac": round(rb / (kernel_ms_alone["raster_resolve"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)}),
-                                   "kernel_ms_mode": "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera%s" % (in_flight, "moving" if moving else "static", "; the frame before the last of 6 queued back to back (overlapped on both sides)" if overlapped else ""),
+                                   "kernel_ms_mode": mode_txt,
                                    "note": "12 B per pixel (8 B key read + 4 B XRGB write) + 8 B per covered pixel (key re-zeroed)"}
-            # The whole frame: fragments x 8 + resolve (above), over the frame time of the timed loop (frames
-            # overlap: the latency-bound setup of one hides behind the HBM kernels of the other)
-            frag = 1.5 * cov
-            algo_bytes = 12.0 * px + 8.0 * cov + 8.0 * frag
-            out["roofline_frame"] = {"bound": "hbm", "achieved": round(algo_bytes / (ms_frame * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
-                                     "unit": "GB/s", "frac": round(algo_bytes / (ms_frame * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-                                     "traffic": measured_traffic(name, [""]) if world == 1 else None,
-                                     "algorithmic_bytes": int(algo_bytes),
-                                     "kernel_ms_sum": round(sum(kernel_ms.get(k, 0.0) for k in ("clear", "raster_setup", "raster_frag", "raster_resolve")), 5)}
+                # The whole frame: fragments x 8 + resolve (above), over the frame time of the timed loop
+                frag = 1.5 * cov
+                algo_bytes = 12.0 * px + 8.0 * cov + 8.0 * frag
+                out["roofline_frame"] = {"bound": "hbm", "achieved": round(algo_bytes / (ms_frame * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
+                                         "unit": "GB/s", "frac": round(algo_bytes / (ms_frame * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                                         "traffic": measured_traffic(name, ["k_cull", "k_raster"]) if world == 1 else None,
+                                         "algorithmic_bytes": int(algo_bytes),
+                                         "kernel_ms_sum": round(sum(kernel_ms.get(k, 0.0) for k in ("clear", "raster_setup", "raster_frag", "raster_resolve")), 5)}
         if dof and kernel_ms.get("dof", 0.0) > 0:
             # the depth-of-field pass: K*K taps x 3 channels x (multiply, add) per pixel, two per packed
             # instruction -- VALU-bound; its issue fraction from the committed PMC pass of this workload

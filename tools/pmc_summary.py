@@ -16,7 +16,7 @@ for which, key, mul in (("fetch", "fetch_bytes", 2.0), ("write", "write_bytes", 
     tot = collections.Counter()
     for f in files:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:80]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:80]
             tot[k] += float(r["Counter_Value"]) * 1024.0 * mul
             n[k] += 1
     for k in tot:
