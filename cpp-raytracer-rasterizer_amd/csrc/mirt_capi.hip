@@ -916,6 +916,8 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         // (host float division is the same IEEE operation the kernels would run per pixel)
         for (int c = 0; c < 3; c++) f.lcol[j][c] = (lights[k].color[c] * lights[k].intensity) / (float)f.samples;
     }
+    f.lights_in_range = 1;
+    for (int j = 0; j < npos; j++) f.lights_in_range &= light_colour_in_range(f.lcol[j]) ? 1 : 0;
     nlights = npos;            // from here on "lights" means light positions
     memcpy(f.indirect, indirect, 12);
     f.y0 = y0; f.y1 = y1; f.row_origin = row_origin;
@@ -1628,6 +1630,8 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
         memcpy(f.lpos[k], lights[k].pos, 12);
         for (int c = 0; c < 3; c++) f.lcol[k][c] = lights[k].color[c] * lights[k].intensity;   // rasteriser.cpp:576
     }
+    f.lights_in_range = 1;
+    for (int k = 0; k < nlights; k++) f.lights_in_range &= light_colour_in_range(f.lcol[k]) ? 1 : 0;
     memcpy(f.indirect, indirect, 12);
     f.y0 = y0; f.y1 = y1; f.row_origin = row_origin;
     f.xrgb = static_cast<uint32_t *>(d_xrgb);

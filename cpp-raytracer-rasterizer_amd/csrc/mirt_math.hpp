@@ -103,4 +103,12 @@ MIRT_HD uint32_t pack_xrgb(v3 c) { return (chan8(c.x) << 16) | (chan8(c.y) << 8)
 // (raytracer.cpp:295, rasteriser.cpp:575).
 MIRT_HD float sphere_area(float r) { return (float)(4 * 3.14159265358979323846 * (double)(r * r)); }
 
+// Whether a light's colour (times its intensity, over the shadow samples) is inside [2^-40, 2^40) in every component: the range in
+// which the kernels may share one refined reciprocal between the three divisions lightColor / A (mirt_math2.hpp: light_geometry2).
+MIRT_HD bool light_colour_in_range(const float *c)
+{
+    for (int k = 0; k < 3; k++) { const float a = c[k] < 0.0f ? -c[k] : c[k]; if (!(a >= 0x1p-40f && a < 0x1p40f)) return false; }
+    return true;
+}
+
 }  // namespace mirt

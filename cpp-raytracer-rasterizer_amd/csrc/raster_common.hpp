@@ -41,7 +41,9 @@ struct SmallSpan {
     float azinv, zstep;
     float ap[3], pstep[3];
     float nrm[3], col[3];                           // triangles[tri].normal (NOT normalised by the rasteriser, :578) and .color
-    int tri, pad[3];
+    int tri;
+    int safe;                                       // every pixel of the span has pos3d and zinv inside the range of div3p_sel (mirt_math2.hpp)
+    int pad[2];
 };
 static_assert(sizeof(SmallSpan) == 80, "row-list record must be 80 bytes (16-byte aligned)");
 
@@ -76,6 +78,7 @@ struct RasterFrame {
     int nlights;
     float lpos[MIRT_MAX_LIGHTS][3];
     float lcol[MIRT_MAX_LIGHTS][3];
+    int lights_in_range;     // every lcol component passes light_colour_in_range (mirt_math.hpp)
     float indirect[3];
     int y0, y1, row_origin;
     uint32_t *xrgb;

@@ -467,12 +467,15 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rr = wave, y = f.y0 + (int)blockIdx.y * SMALL_ROWS + wave;       // this wave's row; no wave waits for another
     if (y >= f.y1) return;
-    int count;
+    // The spans of row y that draw into [xbase, xbase + SMALL_PX): one lane per triangle.  The lane keeps what the depth test
+    // wants -- first pixel, pixel count, a.zinv, the zinv step -- in its registers (the passes fetch them with v_readlane, triangle
+    // by triangle) and files what the shading wants -- the span's 3-D walk, the triangle's normal and colour -- in the wave's LDS
+    // slice under the triangle's number.  seg_mask[s]: the triangles whose span reaches into the 128 pixels of pass s.
+    int sp_first = 0, sp_count = 0;             // pixels x = sp_first + i, 0 <= i < sp_count, clipped to x < W (never produced otherwise: :663, E-2)
+    float sp_azinv = 0.0f, sp_zstep = 0.0f;
+    unsigned long long seg_mask[SMALL_PX / 128];
     {
-        // the spans of row y that draw into [xbase, xbase + SMALL_PX): one lane per triangle, kept in triangle order, as five
-        // 16-byte words each (span constants + the triangle's normal and colour)
         bool take = false;
-        float4 v0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), v1 = v0, v2 = v0, v3 = v0, v4 = v0;
         if (lane < f.n) {
             const TriSetup &st = f.scratch.setup[lane];
             const int r0 = st.r0, rows = st.rows;
@@ -482,55 +485,62 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
                 const float4 a = src[0], b = src[1], c = src[2];      // {ax, dx, azinv, zstep | ap.xyz, pstep.x | pstep.yz, tri, y}
                 const float *t15 = f.tris15 + (size_t)15 * lane;
                 const int ax = __float_as_int(a.x), dx = __float_as_int(a.y);
-                // fragments are x = ax+1 .. ax+dx; those outside [0, W) are never produced (:663, E-2)
-                const long long lo = std::max<long long>((long long)ax + 1, (long long)xbase);
-                const long long hi = std::min<long long>((long long)ax + dx, (long long)std::min(f.W, xbase + SMALL_PX) - 1);
-                take = dx > 0 && lo <= hi;
-                v0 = a; v1 = b;
-                v2 = make_float4(c.x, c.y, t15[9], t15[10]);          // pstep.yz, normal.xy
-                v3 = make_float4(t15[11], t15[12], t15[13], t15[14]);    // normal.z, colour
-                v4 = make_float4(__int_as_float(lane), 0.0f, 0.0f, 0.0f);
+                // fragments are x = ax+1 .. ax+dx (|ax|, dx <= 2^21: RASTER_COORD_LIMIT); those outside [0, W) are never produced
+                sp_first = ax + 1;
+                sp_count = min(dx, f.W - 1 - ax);
+                sp_azinv = a.z; sp_zstep = a.w;
+                take = dx > 0 && sp_count > 0 && sp_first + sp_count > xbase && sp_first < xbase + SMALL_PX;
+                if (take) {
+                    // Both ends of the span's walk in the range of the shared-reciprocal division (mirt_math2.hpp: div3p_sel) and no
+                    // component changing sign => every pixel between them too: a + step * float(i) is monotone in i, roundings included
+                    const float fl = (float)(dx - 1);
+                    const float ze = a.z + a.w * fl, xe = b.x + b.w * fl, ye = b.y + c.x * fl, ze3 = b.z + c.y * fl;
+                    const bool safe = a.z >= DIV3_LO && a.z < DIV3_HI && ze >= DIV3_LO && ze < DIV3_HI &&
+                                      div3_mag_in_range(b.x) && div3_mag_in_range(xe) && (b.x < 0.0f) == (xe < 0.0f) &&
+                                      div3_mag_in_range(b.y) && div3_mag_in_range(ye) && (b.y < 0.0f) == (ye < 0.0f) &&
+                                      div3_mag_in_range(b.z) && div3_mag_in_range(ze3) && (b.z < 0.0f) == (ze3 < 0.0f);
+                    float4 *dst = reinterpret_cast<float4 *>(&s_list[rr][lane]);
+                    dst[0] = a; dst[1] = b;
+                    dst[2] = make_float4(c.x, c.y, t15[9], t15[10]);          // pstep.yz, normal.xy
+                    dst[3] = make_float4(t15[11], t15[12], t15[13], t15[14]);    // normal.z, colour
+                    dst[4] = make_float4(__int_as_float(lane), __int_as_float(safe ? 1 : 0), 0.0f, 0.0f);
+                }
             }
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
-        if (take) {
-            float4 *dst = reinterpret_cast<float4 *>(&s_list[rr][__popcll(m & ((1ull << lane) - 1ull))]);
-            dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4;
-        }
-        count = __popcll(m);
+#pragma unroll
+        for (int seg = 0; seg < SMALL_PX / 128; seg++)
+            seg_mask[seg] = __builtin_amdgcn_ballot_w64(take && sp_first + sp_count > xbase + seg * 128 && sp_first < xbase + seg * 128 + 128);
         // (wave-private LDS: the wave's own accesses execute in order; this only stops the compiler from moving them)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     const v3p camp = splat3(ld3(f.cam));
+#pragma unroll
     for (int seg = 0; seg < SMALL_PX / 128; seg++) {
         // the lane's two pixels are neighbours: both inside or both outside a surface almost always, so a pass whose pixels
         // nothing covers skips the shading whole, and the pair leaves as one 8-byte store
         const int x0 = xbase + seg * 128 + 2 * lane, x1 = x0 + 1;
         if (xbase + seg * 128 >= f.W) break;
         const bool ok0 = x0 < f.W, ok1 = x1 < f.W;
-        // ---- depth test (:603-608) for both pixels against the row's spans, branch-free: the u64 key zinv_bits << 32 |
-        // (~triangle << 6 | list slot) of every span that draws the pixel with zinv > 0 (depthBuffer starts at 0, Update() :188),
-        // maximum kept = largest zinv, lowest triangle among exact ties -- the reference's strict `>` in triangle order ----
-        unsigned long long k0 = 0ull, k1 = 0ull;
-        const int seg_lo = xbase + seg * 128, seg_hi = seg_lo + 127;
-        for (int j = 0; j < count; j++) {
-            const SmallSpan &sp = s_list[rr][j];
-            // (wave-uniform: a span that draws none of this pass's 128 pixels is skipped whole)
-            if (__builtin_amdgcn_readfirstlane(sp.ax) >= seg_hi || (long long)__builtin_amdgcn_readfirstlane(sp.ax) + __builtin_amdgcn_readfirstlane(sp.dx) < seg_lo) continue;
-            const int i0 = x0 - sp.ax - 1, i1 = x1 - sp.ax - 1;                   // Bresenham's i of this pixel (:657)
-            const f2 z = splat2(sp.azinv) + splat2(sp.zstep) * (f2){ (float)i0, (float)i1 };   // :667
-            const uint32_t low = ((0x03FFFFFFu - (uint32_t)sp.tri) << 6) | (uint32_t)j;
-            const bool in0 = ok0 && (unsigned)i0 < (unsigned)sp.dx && z.x > 0.0f, in1 = ok1 && (unsigned)i1 < (unsigned)sp.dx && z.y > 0.0f;
-            const unsigned long long c0 = in0 ? ((unsigned long long)__float_as_uint(z.x) << 32) | low : 0ull;
-            const unsigned long long c1 = in1 ? ((unsigned long long)__float_as_uint(z.y) << 32) | low : 0ull;
-            k0 = c0 > k0 ? c0 : k0;
-            k1 = c1 > k1 ? c1 : k1;
+        // ---- depth test (:603-608) for both pixels against the spans of this pass, in ascending triangle order with the
+        // reference's strict `zinv > depthBuffer[y][x]` (depthBuffer starts at 0, Update() :188): the largest zinv wins, the lowest
+        // triangle among exact ties, NaN never ----
+        float bzf0 = 0.0f, bzf1 = 0.0f;
+        int bj0 = -1, bj1 = -1;
+        for (unsigned long long m = seg_mask[seg]; m; m &= m - 1ull) {
+            const int j = __builtin_ctzll(m);
+            const int first = __builtin_amdgcn_readlane(sp_first, j), cnt = __builtin_amdgcn_readlane(sp_count, j);
+            const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp_azinv), j));
+            const float zs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp_zstep), j));
+            const int i0 = x0 - first, i1 = i0 + 1;                               // Bresenham's i of this pixel (:657)
+            const f2 z = splat2(az) + splat2(zs) * (f2){ (float)i0, (float)i1 };  // :667
+            const bool w0 = (unsigned)i0 < (unsigned)cnt && z.x > bzf0, w1 = (unsigned)i1 < (unsigned)cnt && z.y > bzf1;
+            bzf0 = w0 ? z.x : bzf0; bj0 = w0 ? j : bj0;
+            bzf1 = w1 ? z.y : bzf1; bj1 = w1 ? j : bj1;
         }
-        const uint32_t bz0 = (uint32_t)(k0 >> 32), bz1 = (uint32_t)(k1 >> 32);
-        const int bj0 = k0 ? (int)(k0 & 63ull) : -1, bj1 = k1 ? (int)(k1 & 63ull) : -1;
-        const int bt0 = bj0 >= 0 ? s_list[rr][bj0].tri : -1, bt1 = bj1 >= 0 ? s_list[rr][bj1].tri : -1;
+        const uint32_t bz0 = __float_as_uint(bzf0), bz1 = __float_as_uint(bzf1);
+        const int bt0 = bj0, bt1 = bj1;                                           // (the list slot of a span is its triangle)
 
         // ---- PixelShader (:549-589) of the two winners, packed ----
         v3p colour = splat3(V3(0.0f, 0.0f, 0.0f));  // Update() cleared pixelColours (:189)
@@ -540,28 +550,28 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
 #else
         if (bj0 >= 0 || bj1 >= 0) {
 #endif
-            const SmallSpan &a = s_list[rr][bj0 >= 0 ? bj0 : 0], &b = s_list[rr][bj1 >= 0 ? bj1 : 0];
-            const f2 zinv = { __uint_as_float(bz0), __uint_as_float(bz1) };
-            const f2 fi = { (float)(x0 - a.ax - 1), (float)(x1 - b.ax - 1) };
+            // a pixel nothing covers shades a copy of its neighbour (nobody reads the result): the lane's two halves are then both
+            // real fragments, and whatever holds for the operands of the live one holds for both
+            const int sj0 = bj0 >= 0 ? bj0 : bj1, sj1 = bj1 >= 0 ? bj1 : bj0;
+            const SmallSpan &a = s_list[rr][sj0], &b = s_list[rr][sj1];
+            const f2 zinv = { bj0 >= 0 ? bzf0 : bzf1, bj1 >= 0 ? bzf1 : bzf0 };
+            const f2 fi = { (float)((bj0 >= 0 ? x0 : x1) - a.ax - 1), (float)((bj1 >= 0 ? x1 : x0) - b.ax - 1) };
             const v3p ap = join3(ld3(a.ap), ld3(b.ap)), ps = join3(ld3(a.pstep), ld3(b.pstep));
             const v3p p3 = add3p(ap, scale3p(ps, fi));                              // a.pos3d + pos3d*float(i) (:668)
             const v3p normal = join3(ld3(a.nrm), ld3(b.nrm)), color = join3(ld3(a.col), ld3(b.col));
-            v3p P = V3P(div2(p3.x, zinv), div2(p3.y, zinv), div2(p3.z, zinv));      // pPos3d /= p.zinv (:557)
+            v3p P;                                                                  // pPos3d /= p.zinv (:557); the operands' range is known per span
+            div3p_sel(p3.x, p3.y, p3.z, zinv, __builtin_amdgcn_ballot_w64((a.safe & b.safe) == 0), P.x, P.y, P.z);
             const float *m = f.invrot;                                              // * glm::inverse(cameraRot) (:559): vec * mat
             P = V3P(m[0] * P.x + m[1] * P.y + m[2] * P.z, m[3] * P.x + m[4] * P.y + m[5] * P.z, m[6] * P.x + m[7] * P.y + m[8] * P.z);
             P = add3p(P, camp);                                                     // += cameraPos (:560)
             if (f.fd) fdist = distance3p(P, camp) - splat2(f.focal_plane);          // focalDistances (:563-565)
             v3p result = splat3(V3(0.0f, 0.0f, 0.0f));
             for (int k = 0; k < f.nlights; k++) {
-                const v3p L = splat3(ld3(f.lpos[k]));
-                const f2 r = distance3p(P, L);                                      // :574
-                const f2 A = { sphere_area(r.x), sphere_area(r.y) };                // :575
-                const v3p rDir = normalize3p(sub3p(L, P));                          // :577
-                const v3 lc = ld3(f.lcol[k]);
-                const v3p B = V3P(div2(splat2(lc.x), A), div2(splat2(lc.y), A), div2(splat2(lc.z), A));   // :579
-                const f2 d = dot3p(rDir, normal);                                   // normal NOT re-normalised here (:578)
+                // r = distance(pPos3d, lightPos) (:574), A = 4 pi r^2 (:575), rDir = normalize(lightPos - pPos3d) (:577), B = lightColor / A (:579)
+                const LightGeometry2 lg = light_geometry2(P, ld3(f.lpos[k]), ld3(f.lcol[k]), f.lights_in_range != 0, true, true);
+                const f2 d = dot3p(lg.rDir, normal);                                // normal NOT re-normalised here (:578)
                 const f2 mx = { (d.x < 0.0f) ? 0.0f : d.x, (d.y < 0.0f) ? 0.0f : d.y };   // std::max (:581)
-                result = add3p(result, scale3p(B, mx));
+                result = add3p(result, scale3p(lg.B, mx));
             }
             // currentReflectance(1,1,1) * (result + indirectLightPowerPerArea) * color (:587)
             const v3p lit = mul3p(mul3p(splat3(V3(1.0f, 1.0f, 1.0f)), add3p(result, splat3(ld3(f.indirect)))), color);

@@ -154,6 +154,16 @@ __device__ __forceinline__ void maybe_hit2(const TestDots2 &d, bool *m0, bool *m
     *m1 = fminf(fminf(a.y, b.y), slack.y) >= -2.384185791015625e-07f;
 }
 
+// Whether the three quotients of an accept test (t = e1e2b / e1e2d, u = be2d / e1e2d, v = e1bd / e1e2d, raytracer.cpp:237) may
+// leave the range of the shared-reciprocal division (mirt_math2.hpp: div3p_sel).  For a test the filter let through, be2d and
+// e1bd are at most |e1e2d| (1 + 2^-19) + 2^-21 in magnitude (maybe_hit: a, b >= -2^-22 and a + b <= D (1 + 2^-20) + 2^-22), so
+// |e1e2d| < 2^39 keeps them below 2^40; what is left to test is that none of the three is too small, and e1e2b.
+__device__ __forceinline__ bool exact_quotients_outside(float e1e2b, float pu, float qv, float den)
+{
+    const float lo = fminf(fminf(fabsf(pu), fabsf(qv)), fabsf(den));
+    return !(lo >= DIV3_LO && fabsf(den) < 0x1p39f && div3_mag_in_range(e1e2b));
+}
+
 // The same filter as the quantity it thresholds: a ray may hit iff its half of the result is >= MAYBE_HIT_THRESHOLD (callers that
 // want the verdicts as wave masks compare it themselves).
 constexpr float MAYBE_HIT_THRESHOLD = -2.384185791015625e-07f;
@@ -233,6 +243,7 @@ struct RtFrame {
     int samples;                // soft-shadow samples per light (SOFT_SHADOWS_SAMPLES, raytracer.cpp:41,272-275); 1 = off
     float lpos[MIRT_MAX_LIGHTS][3];
     float lcol[MIRT_MAX_LIGHTS][3];   // P of DirectLight: lights[k].color * lights[k].intensity / samples (raytracer.cpp:282, :296)
+    int lights_in_range;        // every lcol component passes light_colour_in_range (mirt_math.hpp)
     float indirect[3];
     int y0, y1, row_origin;
     uint32_t *xrgb;

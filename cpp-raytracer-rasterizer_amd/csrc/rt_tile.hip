@@ -62,7 +62,9 @@ __device__ __forceinline__ bool box_may_hit(const float4 &r0, const float4 &r1, 
 __device__ __forceinline__ void exact_hit_geo2(const TestDots2 &d, float e1e2b, const float4 *geo, v3 start, bool m0, bool m1,
                                                bool *hit0, bool *hit1, v3p *pos, f2 *dist)
 {
-    const f2 t = div2(splat2(e1e2b), d.den), u = div2(d.pu, d.den), v = div2(d.qv, d.den);     // raytracer.cpp:237
+    f2 t, u, v;
+    div3p_sel(splat2(e1e2b), d.pu, d.qv, d.den,                                                   // raytracer.cpp:237: three quotients over e1e2d
+              __builtin_amdgcn_ballot_w64((m0 && exact_quotients_outside(e1e2b, d.pu.x, d.qv.x, d.den.x)) || (m1 && exact_quotients_outside(e1e2b, d.pu.y, d.qv.y, d.den.y))), t, u, v);
     const f2 uv = u + v;
     *hit0 = m0 && uv.x <= 1.0f && u.x >= 0.0f && v.x >= 0.0f && t.x >= 0.0f;                     // :239
     *hit1 = m1 && uv.y <= 1.0f && u.y >= 0.0f && v.y >= 0.0f && t.y >= 0.0f;
@@ -234,13 +236,11 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
         v3p result = splat3(V3(0.0f, 0.0f, 0.0f)), result2 = result;
         for (int k = 0; k < f.nlights; k++) {
             // DirectLight's term before the shadow test (raytracer.cpp:294-304), both pixels at once
+            // r = distance(pos, lightPos), A = 4 pi r^2, rDir = normalize(lightPos - pos), B = P / A with P = lightColor / samples (:296, divided on the host)
             const v3 L = ld3(f.lpos[k]);
-            const v3p Lp = splat3(L);
-            const f2 r = distance3p(pos, Lp);
-            const f2 A = { sphere_area(r.x), sphere_area(r.y) };
-            const v3 P = ld3(f.lcol[k]);                                     // lightColor / samples (:296), divided on the host
-            const v3p rd = normalize3p(sub3p(Lp, pos));
-            const v3p B = V3P(div2(splat2(P.x), A), div2(splat2(P.y), A), div2(splat2(P.z), A));
+            const LightGeometry2 lg = light_geometry2(pos, L, ld3(f.lcol[k]), f.lights_in_range != 0, hit0, hit1);
+            const f2 r = lg.r;
+            const v3p rd = lg.rDir, B = lg.B;
             const f2 dn = dot3p(rd, nDir);
             const f2 mx = { (dn.x < 0.0f) ? 0.0f : dn.x, (dn.y < 0.0f) ? 0.0f : dn.y };   // std::max(d, 0.0f)
             v3p D = scale3p(B, mx);

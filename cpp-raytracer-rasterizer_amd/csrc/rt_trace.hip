@@ -128,7 +128,8 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
     if (lane < count) {
         const float4 e = s.q[lane];
         uint2 a = s.qa[lane];
-        const float t = e.w / e.x, u = e.y / e.x, v = e.z / e.x;                     // :237
+        float t, u, v;
+        div3_sel(e.w, e.y, e.z, e.x, __builtin_amdgcn_ballot_w64(exact_quotients_outside(e.w, e.y, e.z, e.x)), t, u, v);   // :237: three quotients over e1e2d (queued pairs passed the filter)
         if (u + v <= 1.0f && u >= 0.0f && v >= 0.0f && t >= 0.0f) {                  // :239
             float4 g0, g1, g2;
             if (SHADOW) {
@@ -491,13 +492,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                 v3p result = splat3(V3(0.0f, 0.0f, 0.0f)), result2 = result;
                 for (int k = 0; k < f.nlights; k++) {
                     // DirectLight's term before the shadow test (raytracer.cpp:294-304), both pixels at once
+                    // r = distance(pos, lightPos), A = 4 pi r^2, rDir = normalize(lightPos - pos), B = P / A with P = lightColor / samples (:296, divided on the host)
                     const v3 L = ld3(f.lpos[k]);
-                    const v3p Lp = splat3(L);
-                    const f2 r = distance3p(pos, Lp);
-                    const f2 A = { sphere_area(r.x), sphere_area(r.y) };
-                    const v3 P = ld3(f.lcol[k]);                   // lightColor / samples (:296), divided on the host
-                    const v3p rd = normalize3p(sub3p(Lp, pos));
-                    const v3p B = V3P(div2(splat2(P.x), A), div2(splat2(P.y), A), div2(splat2(P.z), A));
+                    const LightGeometry2 lg = light_geometry2(pos, L, ld3(f.lcol[k]), f.lights_in_range != 0, hitA, hitB);
+                    const f2 r = lg.r;
+                    const v3p rd = lg.rDir, B = lg.B;
                     const f2 dn = dot3p(rd, nDir);
                     const f2 mx = { (dn.x < 0.0f) ? 0.0f : dn.x, (dn.y < 0.0f) ? 0.0f : dn.y };   // std::max(d, 0.0f)
                     v3p D = scale3p(B, mx);

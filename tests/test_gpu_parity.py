@@ -346,6 +346,18 @@ def test_packed_division_equals_the_compilers():
     assert r.returncode == 0 and " 0 mismatching" in r.stdout, r.stdout + r.stderr
 
 
+def test_shared_denominator_division_equals_the_compilers():
+    """div3p / div3 (csrc/mirt_math2.hpp: three IEEE divisions by one denominator sharing the refined reciprocal while every operand
+    is in the middle of the exponent range, the general division otherwise) against `/` on the device: 2^28 in-range triples, random
+    bit patterns, special values, waves with one odd lane -- compared as bits (tools/div3check.hip)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "div3check")
+    assert os.path.exists(exe), "tools/div3check not built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "in range (2^28 triples): 0, random bits: 0, special values: 0, one odd lane per wave: 0" in r.stdout, r.stdout + r.stderr
+
+
 def test_profiling_events_per_stream():
     """mirt_set_profiling: per-kernel GPU times of the last call (mirt_get_stats) and, with two frames in flight, of the call
     before it (mirt_get_previous_kernel_ms: the events of a frame survive the frame that follows it on the other stream)."""

@@ -9,6 +9,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), os.path.join(ROOT, "tests")]
 import mirt                                 # noqa: E402
+if len(sys.argv) > 1:
+    mirt.LIB_PATH = sys.argv[1]             # an alternative build of the library (tools/build_variant.sh)
 from devbuf import DeviceArray              # noqa: E402
 
 W, H = 3840, 2160

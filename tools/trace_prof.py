@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/trace_prof.py [nolight] -- a dozen binned frames of the 100 k soup at 1080p (static camera), for rocprofv3:
+"""tools/trace_prof.py [nolight|1m8k|cornell] [variant.so] -- a dozen binned frames of the 100 k soup at 1080p (static camera), for rocprofv3:
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES ... -d gpurun_out/x -- python3 tools/trace_prof.py"""
 import os
 import sys
@@ -18,11 +18,12 @@ big = "1m8k" in sys.argv                    # BASELINE config 5 (1 M triangles, 
 W, H = (7680, 4320) if big else (1920, 1080)
 lights = np.zeros((0, 7), np.float32) if "nolight" in sys.argv else np.array([[0.0, -0.5, -0.7, 1, 1, 1, 14]], np.float32)
 mirt.init(0)
-mirt.scene_upload(mirt.scene_soup(2, 1000000, 0.02) if big else mirt.scene_soup(1, 100000, 0.05))
-view = mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.0, 1.0), H / 2.0, W, H)
+cornell = "cornell" in sys.argv              # BASELINE config 2: the Cornell box at 1080p (tile kernel)
+mirt.scene_upload(mirt.scene_cornell() if cornell else mirt.scene_soup(2, 1000000, 0.02) if big else mirt.scene_soup(1, 100000, 0.05))
+view = mirt.make_view((0, 0, -3), mirt.rot_from_yaw(0.0, 1.0), float(H), W, H) if cornell else mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.0, 1.0), H / 2.0, W, H)
 x = DeviceArray((H, W), np.uint32)
 for it in range(12):
-    mirt.raytrace_device(view, lights, (0.2, 0.2, 0.2), mirt.RT_BINNED, 0, H, 0, x.ptr, W * 4)
+    mirt.raytrace_device(view, lights, (0.2, 0.2, 0.2), mirt.RT_AUTO if cornell else mirt.RT_BINNED, 0, H, 0, x.ptr, W * 4)
 mirt.sync()
 print(mirt.stats())
 mirt.shutdown()
