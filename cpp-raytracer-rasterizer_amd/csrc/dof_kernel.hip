@@ -15,8 +15,10 @@
 // the data: k_dof_tile stages a (32+K-1) x (64+K-1) tile of pixelColours in LDS; a thread owns eight
 // vertically adjacent outputs and walks the tile rows once, feeding each value it reads to every output whose window
 // holds that row -- each output still sees its taps in the reference's (z, z2) order.  HBM traffic is the
-// algorithmic 16 B read + 4 B written per pixel (plus the tile halo); the kernel is bound by its K*K*6 VALU
-// operations per pixel (no FMA: the reference multiplies, then adds).
+// algorithmic 16 B read + 4 B written per pixel (plus the tile halo): 200 MB per 4K frame, ~40 us on this chip; the K*K*6 VALU
+// operations per pixel (no FMA: the reference multiplies, then adds) are 1472 packed instructions per thread of 1875, 52 us at
+// the issue ceiling.  A workgroup loads, then computes, and the two phases of different workgroups overlap only in part:
+// 74 us measured (4 or 8 outputs per thread, 4 to 6 waves per SIMD: the same).
 #include "dof.hpp"
 
 #include <utility>
@@ -55,26 +57,35 @@ __device__ __forceinline__ void dof_fence2(f2 *fxy, f2 *fz, const float *row)
 }
 
 // One tile row: z = zlo + (RR - p) for output p.  Everything that depends on (RR, c, p) is resolved at compile time.
-// fxy: (r, g) of each output; fz: b of outputs (2q, 2q+1); wo2: their off-centre weights; cur: the K taps of the
-// current tile row as they lie in memory; nxt: where the next row's taps are read to (the two register sets swap roles
-// from row to row: copying next into current cost 24 moves per row, a sixth of the kernel's instructions).
+// fxy: (r, g) of each output; fz: b of outputs (2q, 2q+1); wo2: their off-centre weights; cxy / cz: the K taps of the current
+// tile row ((r, g) pairs and blues); nxy / nz: where the next row's taps are read to (the two register sets swap roles from row
+// to row: copying next into current cost 24 moves per row, a sixth of the kernel's instructions).  The tile is planar per row
+// -- TC (r, g) pairs, then TC blues -- so a thread's K taps are K consecutive 8-byte words and K consecutive floats: 4
+// ds_read2_b64 + 4 ds_read2_b32 per row instead of 24 ds_read_b32, landing in the register pairs the packed arithmetic wants.
 template <int RR, int KT>
 __device__ __forceinline__ void dof_row(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2], const f2 (&wo2)[DOF_PY / 2], const float (&wc)[DOF_PY],
-                                        const float (&wo)[DOF_PY], float (&cur)[3 * KT], float (&nxt)[3 * KT], const float *t0, int pitch)
+                                        const float (&wo)[DOF_PY], f2 (&cxy)[KT], float (&cz)[KT], f2 (&nxy)[KT], float (&nz)[KT],
+                                        const float *t0, int pitch, int boff)
 {
     constexpr int ZC = KT / 2;                        // -ceil(KT / -2.0f): index of the centre tap
     if constexpr (RR + 1 < DOF_PY + KT - 1) {
-        // the reads of row RR+1 are issued (volatile: they stay where they are written) before the arithmetic of row RR
-        typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
-        lds_vfloat *tn = (lds_vfloat *)(t0 + (RR + 1) * pitch);
+        // the reads of row RR+1 are issued before the arithmetic of row RR (the fences on both sides keep them here)
+        // (one address register per row and plane, the taps at small offsets from it: left alone, the compiler derives every
+        // read's address from t0 with an add of its own once the offset no longer fits the instruction)
+        typedef const __attribute__((address_space(3))) float lds_float;
+        typedef const __attribute__((address_space(3))) f2 lds_f2;
+        lds_float *tn = (lds_float *)(t0 + (RR + 1) * pitch), *tb = tn + boff;
+        asm volatile("" : "+v"(tn), "+v"(tb));
 #pragma unroll
-        for (int i = 0; i < 3 * KT; i++) nxt[i] = tn[i];
+        for (int c = 0; c < KT; c++) nxy[c] = *(lds_f2 *)(tn + 2 * c);
+#pragma unroll
+        for (int c = 0; c < KT; c++) nz[c] = tb[c];
     }
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int c = 0; c < KT; c++) {
-        const f2 vxy = { cur[3 * c], cur[3 * c + 1] };
-        const float vz = cur[3 * c + 2];
+        const f2 vxy = cxy[c];
+        const float vz = cz[c];
 #pragma unroll
         for (int p = 0; p < DOF_PY; p++) {
             const int zi = RR - p;
@@ -102,10 +113,10 @@ __device__ __forceinline__ void dof_row(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2],
 
 template <int KT, int... RR>
 __device__ __forceinline__ void dof_rows(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2], const f2 (&wo2)[DOF_PY / 2], const float (&wc)[DOF_PY],
-                                         const float (&wo)[DOF_PY], float (&even)[3 * KT], float (&odd)[3 * KT], const float *t0, int pitch,
-                                         std::integer_sequence<int, RR...>)
+                                         const float (&wo)[DOF_PY], f2 (&exy)[KT], float (&ez)[KT], f2 (&oxy)[KT], float (&oz)[KT],
+                                         const float *t0, int pitch, int boff, std::integer_sequence<int, RR...>)
 {
-    (dof_row<RR, KT>(fxy, fz, wo2, wc, wo, (RR & 1) ? odd : even, (RR & 1) ? even : odd, t0, pitch), ...);
+    (dof_row<RR, KT>(fxy, fz, wo2, wc, wo, (RR & 1) ? oxy : exy, (RR & 1) ? oz : ez, (RR & 1) ? exy : oxy, (RR & 1) ? ez : oz, t0, pitch, boff), ...);
 }
 
 // One pixelColours element by flat index, 0 outside the frame or outside the rows this call rendered.
@@ -121,39 +132,57 @@ __device__ __forceinline__ float dof_fetch(const DofFrame &f, long long flat_px,
 template <int KT>
 __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame f)
 {
-    extern __shared__ float tile[];                   // [TR][TC][3]: pixelColours as it lies in memory
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // KT == 0: [TR][TC][3], pixelColours as it lies in memory; KT > 0: planar rows, see below
     const int K = KT > 0 ? KT : f.K;
     const int zlo = dof_zlo(K);
     const int TR = DOF_TY + K - 1;                    // tile rows
-    const int pitch = (DOF_TX + K - 1) * 3;           // floats per tile row
+    const int TC = DOF_TX + K - 1;                    // tile columns
+    const int pitch = KT > 0 ? ((TC * 3 + 1) & ~1) : TC * 3;   // floats per tile row (even for the planar layout: its (r, g) pairs are read as 8-byte words)
     const int x0 = blockIdx.x * DOF_TX, ty0 = f.y0 + blockIdx.y * DOF_TY;
 
     // stage: tile(r, c) = pixelColours[(ty0 + zlo + r) * W + (x0 + zlo + c)] by FLAT index, as the reference addresses
     // it (a column outside the row wraps into the neighbouring row); 0 outside the frame / the rows rendered.
-    // Every tile row is one contiguous run of floats: a straight copy, one wave per row.
+    // Every tile row is one contiguous run of pixels, one wave per row.
     const long long lo = 3LL * max(0, f.ry0) * f.W, hi = 3LL * min(f.H, f.ry1) * f.W;
     if constexpr (KT > 0) {
-        // all loads of the thread first, then all LDS stores: one round trip to memory instead of one per element
-        constexpr int ROWS = (DOF_TY + KT - 1 + DOF_WAVES - 1) / DOF_WAVES, COLS = ((DOF_TX + KT - 1) * 3 + DOF_TX - 1) / DOF_TX;
-        float v[ROWS][COLS];
+        // The frame's rendered rows [lo, hi) as a range-checked buffer: a load whose byte offset falls outside it returns 0 --
+        // the very rule the taps follow -- so staging needs no comparison and no branch per element (the per-element tests
+        // were 64-bit compares under exec masks: 600 scalar and 500 vector instructions per wave, a fifth of the kernel).
+        // Offsets are 32-bit: an element before `lo` wraps to ~4e9 and is out of range like one beyond `hi` (launch_dof sends
+        // frames of 2^31 bytes or more to k_dof_tile<0>).  A lane loads whole pixels (three floats, each range-checked by itself)
+        // and files them planar: row r holds TC (r, g) pairs, then TC blues.
+        // All loads of the thread first, then all LDS stores: one round trip to memory instead of one per element.
+        constexpr int ROWS = (DOF_TY + KT - 1 + DOF_WAVES - 1) / DOF_WAVES, COLS = (DOF_TX + KT - 1 + DOF_TX - 1) / DOF_TX;
+        typedef float f3 __attribute__((ext_vector_type(3)));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(f.rgb + lo), 0, (int)((hi - lo) * 4), 0x00020000);
+        f3 v[ROWS][COLS];
 #pragma unroll
         for (int j = 0; j < ROWS; j++) {
             const int r = threadIdx.y + j * DOF_WAVES;
-            const long long src = 3 * ((long long)(ty0 + zlo + r) * f.W + (x0 + zlo));
+            const long long src = 3 * ((long long)(ty0 + zlo + r) * f.W + (x0 + zlo)) - lo;     // first float of the tile row, relative to `lo`
+            const uint32_t row_off = (uint32_t)(src * 4);
 #pragma unroll
             for (int k = 0; k < COLS; k++) {
-                const int i = threadIdx.x + k * DOF_TX;
-                const long long s = src + i;
-                v[j][k] = (r < TR && i < pitch && s >= lo && s < hi) ? f.rgb[s] : 0.0f;
+                const int c = threadIdx.x + k * DOF_TX;
+                v[j][k] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(row_off + (uint32_t)c * 12u), 0, 0));
             }
         }
+        // (every load is issued here, before the first store: a load sunk into a guarded store would wait for memory alone)
+#pragma unroll
+        for (int j = 0; j < ROWS; j++)
+#pragma unroll
+            for (int k = 0; k < COLS; k++) asm volatile("" : "+v"(v[j][k]));
 #pragma unroll
         for (int j = 0; j < ROWS; j++) {
             const int r = threadIdx.y + j * DOF_WAVES;
 #pragma unroll
             for (int k = 0; k < COLS; k++) {
-                const int i = threadIdx.x + k * DOF_TX;
-                if (r < TR && i < pitch) tile[r * pitch + i] = v[j][k];
+                const int c = threadIdx.x + k * DOF_TX;
+                // (only the last row group and the last column group can fall outside the tile: the rest is unconditional)
+                if (((j + 1) * DOF_WAVES <= DOF_TY + KT - 1 || r < TR) && ((k + 1) * DOF_TX <= DOF_TX + KT - 1 || c < TC)) {
+                    *reinterpret_cast<f2 *>(tile + r * pitch + 2 * c) = (f2){ v[j][k].x, v[j][k].y };
+                    tile[r * pitch + 2 * TC + c] = v[j][k].z;
+                }
             }
         }
     } else {
@@ -177,14 +206,18 @@ __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame 
     for (int p = 0; p < DOF_PY; p++) {
         const int y = yb + p;
         float fdc = 0.0f;
-        if (y < f.y1) fdc = f.fd[(size_t)y * f.W + x];
+        if constexpr (KT > 0) {
+            // (range-checked like the colours: rows beyond the band read 0)
+            const __amdgpu_buffer_rsrc_t fdsrc = __builtin_amdgcn_make_buffer_rsrc((void *)f.fd, 0, (int)((long long)f.y1 * f.W * 4), 0x00020000);
+            fdc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(fdsrc, (y * f.W + x) * 4, 0, 0));
+        } else if (y < f.y1) fdc = f.fd[(size_t)y * f.W + x];
         const float a = fminf(fabsf(fdc), 1.0f);                              // min(abs(focalDistances[..]), 1.0f)
         wc[p] = 1 - (a * ((totalPixels - 1) / totalPixels));                  // :629
         wo[p] = a * (1.0f / totalPixels);                                     // :631
         fin[p] = V3(0.0f, 0.0f, 0.0f);
     }
-    // lanes read with a stride of 3 floats: odd, so the 64 lanes of a read fall into 64 different banks
-    const float *t0 = tile + (threadIdx.y * DOF_PY) * pitch + threadIdx.x * 3;
+    // KT == 0: lanes read with a stride of 3 floats: odd, so the 64 lanes of a read fall into 64 different banks
+    const float *t0 = tile + (threadIdx.y * DOF_PY) * pitch + threadIdx.x * (KT > 0 ? 2 : 3);
     if constexpr (KT > 0) {
         // Software pipeline over tile rows: the reads of row rr+1 are issued (volatile: they stay where they are
         // written) before the arithmetic of row rr, which covers the LDS latency.  Without this the scheduler either
@@ -197,10 +230,12 @@ __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame 
         for (int p = 0; p < DOF_PY; p++) fxy[p] = (f2){ 0.0f, 0.0f };
 #pragma unroll
         for (int q = 0; q < DOF_PY / 2; q++) { fz[q] = (f2){ 0.0f, 0.0f }; wo2[q] = (f2){ wo[2 * q], wo[2 * q + 1] }; }
-        float even[3 * KT], odd[3 * KT];                  // the taps of even / odd tile rows
+        f2 exy[KT], oxy[KT];                              // the taps of even / odd tile rows
+        float ez[KT], oz[KT];
+        const int boff = 2 * TC - threadIdx.x;            // from the lane's first (r, g) pair to its first blue
 #pragma unroll
-        for (int i = 0; i < 3 * KT; i++) even[i] = t0[i];
-        dof_rows<KT>(fxy, fz, wo2, wc, wo, even, odd, t0, pitch, std::make_integer_sequence<int, DOF_PY + KT - 1>());
+        for (int c = 0; c < KT; c++) { exy[c] = *reinterpret_cast<const f2 *>(t0 + 2 * c); ez[c] = t0[boff + c]; }
+        dof_rows<KT>(fxy, fz, wo2, wc, wo, exy, ez, oxy, oz, t0, pitch, boff, std::make_integer_sequence<int, DOF_PY + KT - 1>());
 #pragma unroll
         for (int p = 0; p < DOF_PY; p++) fin[p] = V3(fxy[p].x, fxy[p].y, (p & 1) ? fz[p / 2].y : fz[p / 2].x);
     } else {
@@ -258,7 +293,7 @@ __global__ __launch_bounds__(256) void k_dof_direct(const DofFrame f)
 
 size_t dof_tile_lds_bytes(int K)
 {
-    return (size_t)(DOF_TY + K - 1) * (DOF_TX + K - 1) * 3 * sizeof(float);
+    return (size_t)(DOF_TY + K - 1) * (((DOF_TX + K - 1) * 3 + 1) & ~1) * sizeof(float);      // (rows padded to an even number of floats)
 }
 
 }  // namespace
@@ -269,7 +304,8 @@ void launch_dof(const DofFrame &d, hipStream_t stream)
     if (rows <= 0 || d.W <= 0) return;
     if (d.K <= DOF_MAX_TILE_K) {
         const dim3 grid((d.W + DOF_TX - 1) / DOF_TX, (rows + DOF_TY - 1) / DOF_TY), block(DOF_TX, DOF_WAVES);
-        if (d.K == 8) hipLaunchKernelGGL(k_dof_tile<8>, grid, block, dof_tile_lds_bytes(8), stream, d);
+        // (k_dof_tile<8> addresses the frame with 32-bit byte offsets)
+        if (d.K == 8 && 12LL * d.W * d.H < (1LL << 31)) hipLaunchKernelGGL(k_dof_tile<8>, grid, block, dof_tile_lds_bytes(8), stream, d);
         else hipLaunchKernelGGL(k_dof_tile<0>, grid, block, dof_tile_lds_bytes(d.K), stream, d);
     } else {
         hipLaunchKernelGGL(k_dof_direct, dim3((d.W + 255) / 256, rows), dim3(256), 0, stream, d);

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# tools/pmc_variants.sh <kernel substring> <profiled script> [its args ...] -- libs <variant.so ...>
+# tools/pmc_variants.sh <kernel substring|all> <profiled script> [its args ...] -- libs <variant.so ...>
 # (GPU box) issue-side counters of ONE kernel for the shipped library and for alternative builds of it (tools/build_variant.sh):
 # e.g.  tools/pmc_variants.sh k_rt_tile2 tools/trace_prof.py cornell -- build/variants/libmirt_x.so
 set -uo pipefail
@@ -13,12 +13,14 @@ for lib in "" "$@"; do
   python3 - $out "$kernel" "${lib:-shipped}" <<'PY'
 import csv, glob, sys, collections
 out, kernel, tag = sys.argv[1:4]
-acc = collections.defaultdict(float); cnt = collections.Counter()
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob(out + "/pmc1/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if kernel not in r["Kernel_Name"]: continue
-        acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
-print(tag.split("/")[-1], {c: round(v / max(1, cnt[c])) for c, v in sorted(acc.items())}, flush=True)
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        if "mirt" not in name or (kernel != "all" and kernel not in name): continue
+        acc[name][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(name, r["Counter_Name"])] += 1
+for name, d in acc.items():
+    print(tag.split("/")[-1], name, {c: round(v / max(1, cnt[(name, c)])) for c, v in sorted(d.items())}, "launches", cnt[(name, "SQ_WAVES")], flush=True)
 PY
   rm -rf $out
 done
