@@ -62,9 +62,9 @@ __device__ __forceinline__ bool box_may_hit(const float4 &r0, const float4 &r1, 
 __device__ __forceinline__ void exact_hit_geo2(const TestDots2 &d, float e1e2b, const float4 *geo, v3 start, bool m0, bool m1,
                                                bool *hit0, bool *hit1, v3p *pos, f2 *dist)
 {
-    f2 t, u, v;
-    div3p_sel(splat2(e1e2b), d.pu, d.qv, d.den,                                                   // raytracer.cpp:237: three quotients over e1e2d
-              __builtin_amdgcn_ballot_w64((m0 && exact_quotients_outside(e1e2b, d.pu.x, d.qv.x, d.den.x)) || (m1 && exact_quotients_outside(e1e2b, d.pu.y, d.qv.y, d.den.y))), t, u, v);
+    // (three quotients over one denominator, but div3p_sel's range test and branch cost this divergent loop more than the shared
+    // reciprocal saves: 23.2 vs 22.3 us per frame)
+    const f2 t = div2(splat2(e1e2b), d.den), u = div2(d.pu, d.den), v = div2(d.qv, d.den);     // raytracer.cpp:237
     const f2 uv = u + v;
     *hit0 = m0 && uv.x <= 1.0f && u.x >= 0.0f && v.x >= 0.0f && t.x >= 0.0f;                     // :239
     *hit1 = m1 && uv.y <= 1.0f && u.y >= 0.0f && v.y >= 0.0f && t.y >= 0.0f;

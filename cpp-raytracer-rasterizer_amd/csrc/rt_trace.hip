@@ -403,6 +403,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     dst[8] = a1.x; dst[10] = a1.y; dst[12] = a1.z; dst[14] = a1.w;
                     dst[16] = a2.x; dst[18] = a2.y; dst[20] = a2.z; dst[22] = __uint_as_float(idx);
                     my_near = a1.w;
+                } else if (lane < 32) {
+                    // a slot its list does not fill: `near` = +inf, so no pixel's record lets it through (the slot's twin in the
+                    // other list may be real, and the step that tests it evaluates this one's stale row beside it)
+                    reinterpret_cast<float *>(s.rows)[sj * 24 + sh + 14] = __builtin_huge_valf();
                 }
                 wave_lds_fence();
                 TM_SEG(1)
@@ -424,7 +428,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     const f2 fm = maybe_hit2_margin(td);
                     const unsigned long long nearA = wballot(!(R3.z > lbA)), nearB = wballot(!(R3.w > lbB));
                     const unsigned long long filtA = wballot(fm.x >= MAYBE_HIT_THRESHOLD), filtB = wballot(fm.y >= MAYBE_HIT_THRESHOLD);
-                    const unsigned long long liveA = ((pmA >> j) & 1u) ? (okmA & nearA) : 0ull, liveB = ((pmB >> j) & 1u) ? (okmB & nearB) : 0ull;
+                    // (a candidate the wave has pruned -- near beyond the record of EVERY pixel of its tile -- fails the per-pixel
+                    // test in every lane, and an unfilled slot carries near = +inf: no need to consult pmA / pmB here)
+                    const unsigned long long liveA = okmA & nearA, liveB = okmB & nearB;
                     const unsigned long long mA = liveA & filtA, mB = liveB & filtB;
                     const bool passA = (mA >> lane) & 1ull, passB = (mB >> lane) & 1ull;
                     ntests += (unsigned)__popcll(liveA) + (unsigned)__popcll(liveB);
