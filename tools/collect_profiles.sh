@@ -10,7 +10,7 @@ stage="${1:-pmc}"
 shift || true
 if [ "$stage" = pmc ]; then
   # (optionally: tools/collect_profiles.sh pmc <workload> ... -- a gpurun call is at most 20 minutes)
-  [ $# -gt 0 ] || set -- soup100k cornell1080 raster4k soup1m8k raster4kdof8
+  [ $# -gt 0 ] || set -- soup100k cornell1080 raster4k soup1m8k raster4kdof8 cornell1080dof8
   for t in "$@"; do
     steps=20; [ $t = soup1m8k ] && steps=4
     tools/prof.sh $t --workload $t --steps $steps --warmup 3 > /dev/null 2>&1; echo "trace $t rc=$?"
@@ -23,6 +23,7 @@ if [ "$stage" = pmc ]; then
   done
 elif [ "$stage" = fuzz ]; then
   tools/ubench > gpurun_out/ubench.txt 2>&1
+  tools/div2check > gpurun_out/divcheck.txt 2>&1; tools/div3check >> gpurun_out/divcheck.txt 2>&1; echo "division checks rc=$?"
   tools/edgebench > gpurun_out/edgebench.txt 2>&1
   python tools/moving_light.py > gpurun_out/moving_light.txt 2>&1; echo "moving light rc=$?"
   python tools/fuzz_binned.py 0 300 6 > gpurun_out/fuzz_binned_vs_brute.txt 2>&1; echo "fuzz rc=$?"

@@ -18,7 +18,7 @@ traffic = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (tools/pm
 issue = {"_comment": "issue-side PMC counters per launch (tools/pmc_valu.sh: two rocprofv3 --pmc passes, kernel-trace only), averaged "
                      "over the launches by tools/pmc_issue_summary.py. MI355X, bench.py defaults.",
          "csrc_sha16": csrc_digest(), "workloads": {}}
-for t in ("cornell1080", "soup100k", "raster4k", "soup1m8k", "raster4kdof8"):
+for t in ("cornell1080", "soup100k", "raster4k", "soup1m8k", "raster4kdof8", "cornell1080dof8"):
     stats = sorted(glob.glob("gpurun_out/prof_%s/trace/*/*_kernel_stats.csv" % t), key=os.path.getmtime)
     if stats:
         shutil.copy(stats[-1], "profiles/%s_rocprof_%s_kernel_stats.csv" % (tag, t))
@@ -29,7 +29,7 @@ if traffic["workloads"]:
     json.dump(traffic, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
 if issue["workloads"]:
     json.dump(issue, open("profiles/%s_pmc_issue.json" % tag, "w"), indent=1)
-for name in ("ubench", "edgebench", "moving_light", "fuzz_binned_vs_brute", "fuzz_small_scenes_vs_oracle", "fuzz_call_sequences", "fuzz_raster_call_sequences"):
+for name in ("ubench", "edgebench", "divcheck", "moving_light", "fuzz_binned_vs_brute", "fuzz_small_scenes_vs_oracle", "fuzz_call_sequences", "fuzz_raster_call_sequences"):
     src = "gpurun_out/%s.txt" % name
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, "profiles/%s_%s.txt" % (tag, name))
