@@ -327,6 +327,49 @@ def test_raster_everything_culled(oracle):
     assert not got["xrgb"].any() and (got["index"] == -1).all() and not got["depth"].any()
 
 
+
+# ---- operands outside the range of the shared-reciprocal divisions / the unscaled square root (csrc/mirt_math2.hpp) ----
+# The kernels then take the general operations (wave-uniform branch); the frame must stay bit-identical either way.
+ODD_LIGHTS = {
+    "zero-and-negative-colour": np.array([[0.0, -0.5, -0.7, 0.0, 1.0, -0.4, 14.0]], np.float32),           # lightColor components 0 and < 0
+    "huge-and-tiny-colour": np.array([[0.0, -0.5, -0.7, 3.0e11, 1.0e-14, 1.0, 14.0]], np.float32),         # 4.2e12 > 2^40, 1.4e-13 < 2^-40
+    "light-on-the-back-wall": np.array([[0.1, 0.2, 1.0 - 2.0e-7, 1.0, 1.0, 1.0, 14.0]], np.float32),        # r^2 < 2^-42 for the pixels around it
+    "light-far-away": np.array([[2.0e5, -3.0e5, -4.0e5, 1.0, 1.0, 1.0, 3.0e12]], np.float32),               # r^2 > 2^36
+    "two-lights-one-odd": np.array([[0.0, -0.5, -0.7, 1.0, 1.0, 1.0, 14.0], [0.3, 0.3, -0.2, 0.0, 2.0, 0.0, 5.0]], np.float32),
+}
+
+
+@pytest.mark.parametrize("light", sorted(ODD_LIGHTS))
+def test_rt_odd_lights_take_the_general_arithmetic(oracle, light):
+    """Tile kernel (Cornell box) and binned trace kernel (soup) with lights whose colour or distance is outside the fast range."""
+    L = ODD_LIGHTS[light]
+    _rt_compare(oracle, mirt.scene_cornell(), (0, 0, -3), oracle.rot_from_yaw(0.0, 1.0), 200.0, 200, 200, L, mode=mirt.RT_AUTO)
+    _rt_compare(oracle, mirt.scene_soup(21, 3000, 0.1), (0.1, 0, -2.2), oracle.rot_from_yaw(0.2, 1.0), 160.0, 320, 200, L, mode=mirt.RT_BINNED)
+
+
+@pytest.mark.parametrize("light", sorted(ODD_LIGHTS))
+def test_raster_odd_lights_take_the_general_arithmetic(oracle, light):
+    """Small-scene rasteriser kernel (Cornell box) and the key-buffer path (soup) with the same lights."""
+    L = ODD_LIGHTS[light]
+    _raster_compare(oracle, mirt.scene_cornell(), (0, 0, -3), oracle.rot_from_yaw(0.0, 1.01), 300.0, 300, 300, L)
+    _raster_compare(oracle, mirt.scene_soup(22, 400, 0.2), (0, 0.1, -2.5), oracle.rot_from_yaw(-0.3, 1.0), 200.0, 320, 200, L)
+
+
+@pytest.mark.parametrize("scale", [1.0e-9, 3.0e-4, 3.0e5])
+def test_scaled_scenes_leave_the_fast_range(oracle, scale):
+    """The whole configuration scaled: at 1e-9 pos3d * zinv products, determinants and squared distances fall below 2^-40 / 2^-42,
+    at 3e5 squared distances, light colours and e1e2b leave the range at the top -- spans, queued pairs and light terms take the general path."""
+    tris = mirt.scene_cornell()
+    tris[:, 0:9] *= np.float32(scale)
+    L = np.array([[0.0, -0.5 * scale, -0.7 * scale, 1.0, 1.0, 1.0, 14.0 * scale * scale]], np.float32)
+    cam = (0.0, 0.0, -3.0 * scale)
+    _rt_compare(oracle, tris, cam, oracle.rot_from_yaw(0.1, 1.0), 200.0, 200, 200, L, mode=mirt.RT_AUTO)
+    _raster_compare(oracle, tris, cam, oracle.rot_from_yaw(0.1, 1.01), 240.0, 240, 240, L)
+    soup = mirt.scene_soup(23, 2500, 0.1)
+    soup[:, 0:9] *= np.float32(scale)
+    _rt_compare(oracle, soup, (0.0, 0.0, -2.0 * scale), oracle.rot_from_yaw(0.0, 1.0), 160.0, 256, 160, L, mode=mirt.RT_BINNED)
+
+
 def test_errors_are_reported_not_fatal():
     with pytest.raises(mirt.MirtError):
         mirt.scene_upload(np.zeros((0, 15), np.float32))
