@@ -17,8 +17,9 @@
 // holds that row -- each output still sees its taps in the reference's (z, z2) order.  HBM traffic is the
 // algorithmic 16 B read + 4 B written per pixel (plus the tile halo): 200 MB per 4K frame, ~40 us on this chip; the K*K*6 VALU
 // operations per pixel (no FMA: the reference multiplies, then adds) are 1472 packed instructions per thread of 1875, 52 us at
-// the issue ceiling.  A workgroup loads, then computes, and the two phases of different workgroups overlap only in part:
-// 74 us measured (4 or 8 outputs per thread, 4 to 6 waves per SIMD: the same).
+// the issue ceiling.  74 us measured: the vector pipes are busy 73 % of it, whatever the structure -- 4 or 8 outputs per thread
+// (4 to 6 waves per SIMD), 24 or 8 LDS reads per tap row, or every wave streaming its own rows through an LDS ring with no
+// barrier at all (a variant built, measured at 73.5 us and removed).
 #include "dof.hpp"
 
 #include <utility>

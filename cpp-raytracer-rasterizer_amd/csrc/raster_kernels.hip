@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     const v3p camp = splat3(ld3(f.cam));
+    const bool planes = f.rgb || f.zinv || f.fd || f.index;
 #pragma unroll
     for (int seg = 0; seg < SMALL_PX / 128; seg++) {
         // the lane's two pixels are neighbours: both inside or both outside a surface almost always, so a pass whose pixels
@@ -553,14 +554,24 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
             // a pixel nothing covers shades a copy of its neighbour (nobody reads the result): the lane's two halves are then both
             // real fragments, and whatever holds for the operands of the live one holds for both
             const int sj0 = bj0 >= 0 ? bj0 : bj1, sj1 = bj1 >= 0 ? bj1 : bj0;
-            const SmallSpan &a = s_list[rr][sj0], &b = s_list[rr][sj1];
+            // The two spans' records word by word (SmallSpan as 20 words), each word of span a beside the same word of span b: read
+            // one by one (volatile), a pair lands in the two registers the packed arithmetic reads it from.  As four 16-byte reads
+            // per span the values arrive span-major and ~20 v_mov per pass re-pair them -- a vector instruction each, where the
+            // extra LDS reads cost next to nothing.
+            typedef const volatile __attribute__((address_space(3))) float lds_vfloat;
+            lds_vfloat *wa = (lds_vfloat *)reinterpret_cast<const float *>(&s_list[rr][sj0]);
+            lds_vfloat *wb = (lds_vfloat *)reinterpret_cast<const float *>(&s_list[rr][sj1]);
+#define SPAN_PAIR(w) ((f2){ wa[w], wb[w] })
+            const int axa = __float_as_int(wa[0]), axb = __float_as_int(wb[0]);
+            const int safe2 = __float_as_int(wa[17]) & __float_as_int(wb[17]);
             const f2 zinv = { bj0 >= 0 ? bzf0 : bzf1, bj1 >= 0 ? bzf1 : bzf0 };
-            const f2 fi = { (float)((bj0 >= 0 ? x0 : x1) - a.ax - 1), (float)((bj1 >= 0 ? x1 : x0) - b.ax - 1) };
-            const v3p ap = join3(ld3(a.ap), ld3(b.ap)), ps = join3(ld3(a.pstep), ld3(b.pstep));
+            const f2 fi = { (float)((bj0 >= 0 ? x0 : x1) - axa - 1), (float)((bj1 >= 0 ? x1 : x0) - axb - 1) };
+            const v3p ap = V3P(SPAN_PAIR(4), SPAN_PAIR(5), SPAN_PAIR(6)), ps = V3P(SPAN_PAIR(7), SPAN_PAIR(8), SPAN_PAIR(9));
             const v3p p3 = add3p(ap, scale3p(ps, fi));                              // a.pos3d + pos3d*float(i) (:668)
-            const v3p normal = join3(ld3(a.nrm), ld3(b.nrm)), color = join3(ld3(a.col), ld3(b.col));
+            const v3p normal = V3P(SPAN_PAIR(10), SPAN_PAIR(11), SPAN_PAIR(12)), color = V3P(SPAN_PAIR(13), SPAN_PAIR(14), SPAN_PAIR(15));
+#undef SPAN_PAIR
             v3p P;                                                                  // pPos3d /= p.zinv (:557); the operands' range is known per span
-            div3p_sel(p3.x, p3.y, p3.z, zinv, __builtin_amdgcn_ballot_w64((a.safe & b.safe) == 0), P.x, P.y, P.z);
+            div3p_sel(p3.x, p3.y, p3.z, zinv, __builtin_amdgcn_ballot_w64(safe2 == 0), P.x, P.y, P.z);
             const float *m = f.invrot;                                              // * glm::inverse(cameraRot) (:559): vec * mat
             P = V3P(m[0] * P.x + m[1] * P.y + m[2] * P.z, m[3] * P.x + m[4] * P.y + m[5] * P.z, m[6] * P.x + m[7] * P.y + m[8] * P.z);
             P = add3p(P, camp);                                                     // += cameraPos (:560)
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
             // Update() paints every pixel black (:190); CalculateDOF then draws the interior only (:491-493)
             const bool interior = x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1;
             word[h] = interior ? pack_xrgb(c) : 0u;
-            if (!(h ? ok1 : ok0)) continue;
+            if (!planes || !(h ? ok1 : ok0)) continue;                  // (one wave-uniform test for the optional planes together)
             const size_t px = (size_t)y * f.W + x;
             if (f.rgb) st3(f.rgb + 3 * px, c);
             if (f.zinv) f.zinv[px] = __uint_as_float(h ? bz1 : bz0);
