@@ -93,19 +93,24 @@ __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__res
 // wave took the frame from 103 to 84 us): 16 staged candidates per tile, (u, v) instead of the hit point.
 constexpr int TR_STAGE = MIRT_TR_STAGE;          // candidates staged per chunk and tile (lanes 0..15 stage tile A's, 16..31 tile B's)
 constexpr int TR_DRAIN = 64;                     // the exact stage runs when this many pairs are queued: one pair per lane
-constexpr int TR_QUEUE = 128;                    // queue slots: fewer than TR_DRAIN are queued when a step appends (<= 64 per tile)
+constexpr int TR_QUEUE = 96;                     // queue slots: fewer than TR_DRAIN are queued when a step appends (<= 64 per tile; a step
+                                                 // whose pairs do not fit drains first, tile by tile if need be)
 constexpr int TR_PIX = 128;                      // pixels of a wave: tile A = 0..63, tile B = 64..127
 static_assert(TR_STAGE == 16, "the staging lanes are split 16 / 16 between the two tiles");
 
+// 8064 bytes per wave: 20 waves (5 per SIMD) fit the CU's 160 KB.
 struct TrWaveLds {
     float4 rows[TR_STAGE * 6];        // origin rows of the staged candidates, tile A's and tile B's interleaved float by float
     float4 geo[TR_STAGE * 2 * 3];     // their geometry rows: slot = 16 * tile + position in the chunk
     float4 q[TR_QUEUE];               // {e1e2d, be2d, e1bd, e1e2b} of a queued (ray, candidate) pair
     unsigned long long best[TR_PIX];  // wavefront min-t key of the pixel's closest accepted hit (this sub-ray)
     uint2 qa[TR_QUEUE];               // {pixel of the pair | staging slot of its candidate << 8 (primary rays), triangle index}
-    float px[TR_PIX], py[TR_PIX], pz[TR_PIX];   // the hit point that belongs to best[] (:241)
-    float thr[TR_PIX];                // shadow rays: r * 0.99f (:313)
-    uint32_t flag[TR_PIX];            // primary: some triangle was accepted (ClosestIntersection's return value); shadow: occluded
+    union {
+        float px[TR_PIX];             // primary rays: the hit point that belongs to best[] (:241), read into registers at the merge ...
+        float thr[TR_PIX];            // ... shadow rays, afterwards: r * 0.99f (:313)
+    };
+    float py[TR_PIX], pz[TR_PIX];
+    uint8_t flag[TR_PIX];             // primary: some triangle was accepted (ClosestIntersection's return value); shadow: occluded
 };
 static_assert(sizeof(TrWaveLds) % 16 == 0, "per-wave LDS slice must keep 16-byte alignment");
 
@@ -145,9 +150,9 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
             const v3 p = add3(add3(v0, scale3(e1, u)), scale3(e2, v));              // :241
             const float dist = distance3(start, p);                                  // :242
             if (SHADOW) {
-                if (dist < s.thr[a.x]) s.flag[a.x] = 1u;                             // :313-314
+                if (dist < s.thr[a.x]) s.flag[a.x] = 1;                             // :313-314
             } else {
-                s.flag[a.x] = 1u;                                                    // `intersection = true` (:251)
+                s.flag[a.x] = 1;                                                     // `intersection = true` (:251)
                 const unsigned long long key = min_t_key(dist, (int)a.y);
                 atomicMin(&s.best[a.x], key);                                        // :243-247, order-free
                 // the pair that holds the record now also owns the stored hit point (keys are unique per pixel: one
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
             // the filter on it.  The lists come roughly front to back (depth shells in the sort key), so after the first
             // drains most of a list is skipped.  The records are only updated by drains, i.e. the bounds lag -- never the result.
             s.best[lane] = MIN_T_NONE; s.best[lane + 64] = MIN_T_NONE;
-            s.flag[lane] = 0u; s.flag[lane + 64] = 0u;
+            s.flag[lane] = 0; s.flag[lane + 64] = 0;
             ncand += nokA * nA + nokB * nB;
             float lbA = FLT_MAX, lbB = FLT_MAX;            // distance of the sub-ray's record so far
             float tbA = FLT_MAX, tbB = FLT_MAX;            // their maxima over the tile's pixels (wave-uniform)
@@ -432,11 +437,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     // test in every lane, and an unfilled slot carries near = +inf: no need to consult pmA / pmB here)
                     const unsigned long long liveA = okmA & nearA, liveB = okmB & nearB;
                     const unsigned long long mA = liveA & filtA, mB = liveB & filtB;
-                    const bool passA = (mA >> lane) & 1ull, passB = (mB >> lane) & 1ull;
+                    const bool passA0 = (mA >> lane) & 1ull, passB = (mB >> lane) & 1ull;
                     ntests += (unsigned)__popcll(liveA) + (unsigned)__popcll(liveB);
                     if (mA | mB) {
-                        const int cA = __popcll(mA), cB = __popcll(mB);
-                        if (qn + cA + cB > TR_QUEUE) { TM_SEG(2) tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; ndrains++; TM_SEG(3) }   // (rare: no room for this step)
+                        int cA = __popcll(mA);
+                        const int cB = __popcll(mB);
+                        bool passA = passA0;
+                        if (qn + cA + cB > TR_QUEUE) {                             // (rare: no room for this step)
+                            TM_SEG(2)
+                            if (qn) { tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; ndrains++; }
+                            if (cA + cB > TR_QUEUE) {                              // the step alone does not fit: tile A's pairs go first
+                                if (passA) {
+                                    const int at = wave_rank(mA);
+                                    s.q[at] = make_float4(td.den.x, td.pu.x, td.qv.x, R1.z);
+                                    s.qa[at] = make_uint2((uint32_t)lane | ((uint32_t)j << 8), __float_as_uint(R5.z));
+                                }
+                                tr_drain<false>(s, lane, cA, geo4, cam); ndrains++;
+                                passA = false; cA = 0;
+                            }
+                            TM_SEG(3)
+                        }
                         if (passA) {
                             const int at = qn + wave_rank(mA);
                             s.q[at] = make_float4(td.den.x, td.pu.x, td.qv.x, R1.z);
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
             // ... merged into the pixel's running record exactly as the sequential `>=` sweep would (:243): the
             // sub-ray's best replaces the record when it is at least as close (a later sub-ray wins exact ties)
             const unsigned long long keyA = s.best[lane], keyB = s.best[lane + 64];
-            const bool anyA = s.flag[lane] != 0u, anyB = s.flag[lane + 64] != 0u;     // ClosestIntersection's return value
+            const bool anyA = s.flag[lane] != 0, anyB = s.flag[lane + 64] != 0;     // ClosestIntersection's return value
             if (anyA && bdA >= min_t_dist(keyA)) {
                 bdA = min_t_dist(keyA); biA = min_t_index(keyA);
                 posA = V3(s.px[lane], s.py[lane], s.pz[lane]);       // the hit point as the exact stage computed it (:241)
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     TM_SEG(5)
                     wave_lds_fence();
                     s.thr[lane] = thr.x; s.thr[lane + 64] = thr.y;
-                    s.flag[lane] = 0u; s.flag[lane + 64] = 0u;
+                    s.flag[lane] = 0; s.flag[lane + 64] = 0;
                     // the candidates of each shadow ray: the rows of its light-cube bin, shells 0 .. shell(0.99 r) -- a row of a
                     // later shell has near > 0.99 r (bin_shell_of is monotone in its argument) and cannot occlude (:313)
                     uint32_t eA = 0, endA = 0, eB = 0, endB = 0;
@@ -564,6 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                         const unsigned long long m = wballot(queue);
                         bool occ = sure;
                         if (m) {
+                            if (qn + __popcll(m) > TR_QUEUE) { tr_drain<true>(s, lane, qn, geo4, L, row_tri); qn = 0; ndrains++; }   // (rare: no room for this step)
                             if (queue) {
                                 const int at = qn + wave_rank(m);
                                 s.q[at] = make_float4(td.den, td.pu, td.qv, c0.w);
@@ -574,7 +595,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                                 TM_SEG(7)
                                 do { tr_drain_full<true>(s, lane, qn, geo4, L, row_tri); ndrains++; } while (qn >= TR_DRAIN);
                                 TM_SEG(8)
-                                occ = occ || (act && s.flag[pix] != 0u);         // found occluded: the rest of this list is moot
+                                occ = occ || (act && s.flag[pix] != 0);         // found occluded: the rest of this list is moot
                             }
                         }
                         if (sure) { if (pix < 64u) occA = true; else occB = true; }
@@ -590,8 +611,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     if (qn) { tr_drain<true>(s, lane, qn, geo4, L, row_tri); qn = 0; ndrains++; }
                     TM_SEG(8)
                     // occluded (:313-314); any-hit is exact
-                    if (occA || s.flag[lane] != 0u) { D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f; }
-                    if (occB || s.flag[lane + 64] != 0u) { D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f; }
+                    if (occA || s.flag[lane] != 0) { D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f; }
+                    if (occB || s.flag[lane + 64] != 0) { D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f; }
                     result = add3p(result, D);                     // (:319)
                     if ((k + 1) % f.samples == 0) result2 = add3p(result2, result);   // (:322) after each light's samples
                 }
