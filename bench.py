@@ -71,15 +71,20 @@ SUB_RESULTS_SHARDED = ("soup1m8k",)                       # ... of a --gpus N > 
 
 
 def csrc_digest():
-    """sha256 (first 16 hex digits) over the kernel sources: what a committed PMC summary must have been profiled at."""
+    """sha256 (first 16 hex digits) over the kernel sources' CODE -- comments and blank space stripped, so that rewording a comment
+    does not disown the counters -- : what a committed PMC summary must have been profiled at."""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cpp-raytracer-rasterizer_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".hpp", ".cpp")):
             h.update(name.encode())
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(f.read())
+            with open(os.path.join(d, name), "r", errors="replace") as f:
+                text = f.read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)        # block comments
+            text = re.sub(r"//[^\n]*", "", text)                       # line comments (no string literal in csrc/ holds "//")
+            h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__res
 #ifndef MIRT_TR_STAGE
 #define MIRT_TR_STAGE 16
 #endif
-// What a wave keeps in LDS decides how many waves share a CU and hide each other's latencies (round 2: 8.4 -> 5.4 KB per
-// wave took the frame from 103 to 84 us): 16 staged candidates per tile, (u, v) instead of the hit point.
+// What a wave keeps in LDS decides how many waves share a CU and what else fits beside them (round 2: 8.4 -> 5.4 KB per wave
+// took the frame from 103 to 84 us; round 3, two tiles per wave: 9728 -> 8064 bytes lets the sort's workgroups run beside
+// the trace waves of the frames in flight): 16 staged candidates per tile with their geometry rows, a queue of 96 pairs.
 constexpr int TR_STAGE = MIRT_TR_STAGE;          // candidates staged per chunk and tile (lanes 0..15 stage tile A's, 16..31 tile B's)
 constexpr int TR_DRAIN = 64;                     // the exact stage runs when this many pairs are queued: one pair per lane
 constexpr int TR_QUEUE = 96;                     // queue slots: fewer than TR_DRAIN are queued when a step appends (<= 64 per tile; a step
