@@ -96,8 +96,6 @@ __device__ __forceinline__ void div3p_sel(f2 n0, f2 n1, f2 n2, f2 d, unsigned lo
 {
 #if defined(MIRT_DIV3_MODE) && MIRT_DIV3_MODE == 0          // (A/B builds: the general division everywhere)
     q0 = div2(n0, d); q1 = div2(n1, d); q2 = div2(n2, d);
-#elif defined(MIRT_DIV3_MODE) && MIRT_DIV3_MODE == 2        // (A/B builds, NOT exact: the shared reciprocal without the range test)
-    div3p_fast(n0, n1, n2, d, q0, q1, q2);
 #else
     if (__builtin_expect(outside == 0ull, 1)) div3p_fast(n0, n1, n2, d, q0, q1, q2);
     else { q0 = div2(n0, d); q1 = div2(n1, d); q2 = div2(n2, d); }
