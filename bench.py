@@ -131,6 +131,28 @@ def measured_valu_instructions(workload, kernel_prefix):
     return None
 
 
+def measured_counter(workload, kernel_prefix, counter):
+    """Any counter of the named kernel from the same committed pass (per launch), or None."""
+    doc = committed_profile("%s_pmc_issue.json" % ROUND)
+    for k, v in ((doc or {}).get("workloads", {}).get(workload, {})).items():
+        if kernel_prefix in k and counter in v:
+            return float(v[counter])
+    return None
+
+
+def all_kinds_issue(workload, kernel_prefix, kernel_ms):
+    """Issue-active slots of ANY instruction kind (SQ_ACTIVE_INST_ANY: vector, scalar, LDS, memory, branch, wait; equals the
+    instruction count for vector instructions, counts an LDS / memory instruction that holds its pipe longer more than once) per
+    launch over the kernel's duration, per SIMD and clock: how busy the issue side as a whole is."""
+    n = measured_counter(workload, kernel_prefix, "SQ_ACTIVE_INST_ANY")
+    if not n or kernel_ms <= 0:
+        return None
+    ipc = n / (kernel_ms * 1e-3 * 2.4e9 * 1024)
+    return {"instructions_per_launch": int(n), "achieved": round(ipc, 4), "vector_stream_rate": ISSUE_CEILING, "ratio": round(ipc / ISSUE_CEILING, 4),
+            "unit": "issue-active slots of any instruction kind/clk/SIMD", "source": "profiles/%s_pmc_issue.json (SQ_ACTIVE_INST_ANY)" % ROUND,
+            "note": "against the rate measured for pure vector streams; kinds overlap and long-held LDS / memory instructions count more than once, so a mixed stream may exceed it"}
+
+
 def measured_valu_per_frame(workload):
     """VALU instructions of ALL per-frame kernels of the workload (every kernel the PMC pass saw more than twice: the
     per-scene table builders run once), per frame, from the same committed pass; or None."""
@@ -594,6 +616,9 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                                  "lane_slots_per_test": round(insts * 64.0 / max(tests_rank, 1.0), 1),
                                                  "lane_slots_per_candidate": round(insts * 64.0 / max(float(st["candidates"]), 1.0), 1),
                                                  "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}
+                # every instruction kind over the launch ALONE on the device: the stream as a whole against the issue rate
+                if kernel_ms_alone and kernel_ms_alone.get("trace", 0.0) > 0:
+                    out["roofline"]["valu_issue"]["all_kinds_alone"] = all_kinds_issue(name, kname, kernel_ms_alone["trace"])
                 # ... and of the whole frame: launches of consecutive frames overlap (frames in flight), so what the chip's vector
                 # pipes did per frame is every per-frame kernel's instructions over the FRAME time -- the roofline of the loop
                 per_frame = measured_valu_per_frame(name)
@@ -653,6 +678,8 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                                      "unit": "wave-instr/clk/SIMD", "frac": round(ipc / ISSUE_CEILING, 4),
                                                      "lane_slots_per_pixel": round(insts * 64.0 / band_px, 1),
                                                      "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}
+                    if kernel_ms_alone and kernel_ms_alone.get("raster_resolve", 0.0) > 0:
+                        out["roofline"]["valu_issue"]["all_kinds_alone"] = all_kinds_issue(name, "k_raster_small", kernel_ms_alone["raster_resolve"])
                     per_frame = measured_valu_per_frame(name)
                     if per_frame:
                         fipc = per_frame / (ms_frame * 1e-3 * 2.4e9 * 1024)
