@@ -200,7 +200,9 @@ struct Ctx {
     uint64_t culled_ver[MAX_FLIGHT] = {};        // what each copy holds: the number of the cull call (or upload) it comes from
     uint64_t cull_calls = 0;
     hipEvent_t ev_cull_read[MAX_FLIGHT] = {};    // per stream: its last copy OUT of another stream's flags has been made ...
-    int cull_read_src[MAX_FLIGHT] = { -1, -1, -1, -1 };   // ... of this copy (-1: none pending); the next cull step into it waits
+    uint32_t cull_read_src[MAX_FLIGHT] = {};     // ... bit c: the stream has copied out of copy c since a cull step into c last waited for it
+                                                 // (the event is re-recorded behind every such copy, and a stream runs in order: waiting
+                                                 // for the latest record covers every earlier read of that stream)
     RtScratch rt[MAX_FLIGHT];                    // per-stream tables of the non-tile ray-trace paths (frames in flight)
     GeoRow *d_geo = nullptr;                     // n geometry rows (built by mirt_scene_upload)
     ShadeRow *d_shade = nullptr;                 // n shading rows (likewise)
@@ -1202,7 +1204,7 @@ extern "C" int mirt_init(int device)
         HIP_TRY(hipStreamCreateWithFlags(&g.streams[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_order[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_cull_read[i], hipEventDisableTiming));
-        g.cull_read_src[i] = -1;
+        g.cull_read_src[i] = 0u;
     }
     g.stream = g.streams[0];
     g.in_flight = 1;
@@ -1423,9 +1425,9 @@ extern "C" int mirt_cull_device(const mirt_view *view, int flags)
     hipStream_t st = g.streams[half];
     (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (see call_begin)
     for (int r = 0; r < MAX_FLIGHT; r++)         // a frame of another stream may still be copying this copy's previous flags
-        if (g.cull_read_src[r] == half && r != half) {
+        if ((g.cull_read_src[r] >> half & 1u) && r != half) {
             HIP_TRY(hipStreamWaitEvent(st, g.ev_cull_read[r], 0));
-            g.cull_read_src[r] = -1;
+            g.cull_read_src[r] &= ~(1u << half);
         }
     hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.d_tris, g.n, cp, g.d_culled + (size_t)half * g.n);
     HIP_TRY(hipGetLastError());
@@ -1610,7 +1612,7 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
         HIP_TRY(hipMemcpyAsync(g.d_culled + (size_t)g.si * g.n, g.d_culled + (size_t)from * g.n, (size_t)g.n, hipMemcpyDeviceToDevice, g.stream));
         g.culled_ver[g.si] = g.culled_ver[from];
         HIP_TRY(hipEventRecord(g.ev_cull_read[g.si], g.stream));       // (a later cull step into copy `from` must not overtake this read)
-        g.cull_read_src[g.si] = from;
+        g.cull_read_src[g.si] |= 1u << from;
     }
     g.pending_is_rt = false;
     if (y1 == y0) { call_end(); return MIRT_OK; }

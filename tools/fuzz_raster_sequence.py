@@ -37,6 +37,7 @@ for seed in range(first, first + count):
             n = int(rng.choice([30, 200, 1500, 4096, 4097, 6000]))
             scene = mirt.scene_cornell() if n == 30 else mirt.scene_soup(int(rng.randint(1 << 30)), n, float(rng.choice([0.05, 0.15, 0.4])))
             mirt.scene_upload(scene)
+            cur_culled = np.zeros(len(scene), np.uint8)
         if rng.rand() < 0.15:
             mirt.sync()
             in_flight = int(rng.choice([1, 2, 3, 4]))
@@ -49,20 +50,22 @@ for seed in range(first, first + count):
             cam = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-3.2, -1.0)))
             rot = o.rot_from_yaw(float(rng.uniform(-0.5, 0.5)), 1.01)
             focal = float(rng.uniform(0.6, 1.2)) * H
-            flags = int(rng.randint(4))
-            culled = o.cull(scene, cam, rot, focal, W, H, flags)
-            want = o.rasterise(scene, culled, cam, rot, focal, W, H, L)["xrgb"]
+            # the cull step is optional: a frame drawn without it uses the flags of the most recent one (of the upload: none culled)
+            flags = int(rng.randint(4)) if rng.rand() < 0.7 else -1
+            if flags >= 0:
+                cur_culled = o.cull(scene, cam, rot, focal, W, H, flags)
+            want = o.rasterise(scene, cur_culled, cam, rot, focal, W, H, L)["xrgb"]
             run.append((mirt.make_view(cam, rot, focal, W, H), flags, want))
         pending = []
         for (v, flags, want) in run:
             bi = k % 3; k += 1
             banded = rng.rand() < 0.25
-            mirt.cull_device(v, flags)                      # the flags of the NEXT call (with two frames in flight: of its stream)
+            if flags >= 0:
+                mirt.cull_device(v, flags)                  # the flags of the NEXT call (with several frames in flight: of its stream)
             if banded:
                 ys = int(rng.randint(1, H - 1))
                 mirt.rasterise_device(v, L, IND, 0, ys, 0, outs[bi].ptr, W * 4)
-                mirt.cull_device(v, flags)                  # ... so a frame drawn as two calls culls before each of them
-                mirt.rasterise_device(v, L, IND, ys, H, 0, outs[bi].ptr, W * 4)
+                mirt.rasterise_device(v, L, IND, ys, H, 0, outs[bi].ptr, W * 4)   # (the second call lands on another stream and fetches the flags)
             else:
                 if rng.rand() < 0.3:                        # a ray-traced frame takes the turn the cull step expected: the flags must follow the rasteriser
                     mirt.raytrace_device(v, L, IND, mirt.RT_AUTO, 0, H, 0, scratch.ptr, W * 4)
