@@ -13,18 +13,20 @@ region, as the reference's own loop pays it (Draw() runs only when the view chan
 same loop with one fixed view beside it.
 
 Workloads (BASELINE.json `configs`):
-    cornell1080  (default, configs[1], the config the metric is quoted on) Cornell box, 1920x1080, primary + shadow rays
-    soup100k     (configs[2], the north-star target) 100k random triangles, 1920x1080
+    soup100k     (default; configs[2], the north-star target) 100k random triangles, 1920x1080, one light
+    cornell1080  (configs[1], the config the reference's own number would be quoted on) Cornell box, 1920x1080, primary + shadow rays
     raster4k     (configs[3]) rasteriser, Cornell box, 3840x2160
     cornell500   (configs[0]) the reference's own 500x500 case
     soup1m8k     (configs[4]) 1M random triangles, 7680x4320 (meant for 8 GPUs)
     cornell1080soft16 / cornell1080aa3 / cornell1080dof8 / raster4kdof8   SURVEY 8(f) ranks 1-3 switched on
-With no --workload the line is cornell1080 and carries `sub_results` for soup100k and raster4k (shorter runs of the same
-loop), so one driver run times the north-star config and the rasteriser too.
+With no --workload the line is soup100k (binned: bit-identical to brute force, tests/test_gpu_baseline_configs.py) and carries
+`sub_results` for cornell1080, raster4k, soup1m8k and `soup100k_brute` -- ONE frame of the same workload through the LDS-tiled
+brute-force kernel, the literal wording of configs[2] and the one kernel whose flop count is the reference's (rays x triangles x 60).
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the frame is split into N bands of rows; every rank
-renders its band and the XRGB bands are gathered on rank 0 over RCCL ("scaling": "strong"); frames that render in
-microseconds travel 32 to a gather.  MIRT_BENCH_REHEARSAL=1 runs that control flow with every rank on device 0 (gloo,
+With --gpus N > 1 (`python bench.py --gpus N` starts its own ranks; under the driver's torch.distributed.run it reads RANK /
+LOCAL_RANK / WORLD_SIZE) the frame is split into N bands of rows -- of equal estimated cost where the frame is binned
+(MIRT_PARTITION_WEIGHTED), of equal height otherwise; every rank renders its band and the XRGB bands are gathered on rank 0 over
+RCCL ("scaling": "strong"); frames that render in microseconds travel 32 to a gather.  MIRT_BENCH_REHEARSAL=1 runs that control flow with every rank on device 0 (gloo,
 host-staged gathers) and checks the assembled frames against a single-GPU frame -- not a measurement.
 """
 import argparse
@@ -70,15 +72,20 @@ SUB_RESULTS = ("cornell1080", "raster4k", "soup1m8k")     # embedded in the defa
 SUB_RESULTS_SHARDED = ("soup1m8k",)                       # ... of a --gpus N > 1 run: BASELINE configs[4], the config the band split is for
 
 
+HOST_ONLY_SOURCES = ("mirt_capi.hip", "comm.cpp", "comm.hpp", "scene_host.cpp")      # no device code a counter could have counted
+
+
 def csrc_digest():
-    """sha256 (first 16 hex digits) over the kernel sources' CODE -- comments and blank space stripped, so that rewording a comment
-    does not disown the counters -- : what a committed PMC summary must have been profiled at."""
+    """sha256 (first 16 hex digits) over the DEVICE code's text -- the kernel sources and their headers, comments and blank space
+    stripped, so that rewording a comment or touching host code does not disown the counters -- : what a committed PMC summary must
+    have been profiled at.  Taken ON THE GPU BOX when the counters are collected (tools/collect_profiles.sh writes it beside each
+    summary; tools/store_profiles.py only copies it), never recomputed when the files are stored."""
     import hashlib
     import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cpp-raytracer-rasterizer_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp", ".cpp")):
+        if name.endswith((".hip", ".hpp", ".cpp")) and name not in HOST_ONLY_SOURCES:
             h.update(name.encode())
             with open(os.path.join(d, name), "r", errors="replace") as f:
                 text = f.read()
@@ -91,41 +98,48 @@ def csrc_digest():
 _stale_warned = set()
 
 
-def committed_profile(name):
-    """A committed PMC summary -- or None, with a warning, when it was profiled at other kernel sources than the ones running
-    (tools/store_profiles.py stamps `csrc_sha16`): a counter read from a file must not outlive the kernel it counted."""
+def committed_profile(name, workload):
+    """The counters of one workload from a committed PMC summary -- or {} with a warning, when they were collected at other
+    kernel sources than the ones running (`stamps[workload]`, the digest taken on the GPU box at collection time): a counter read
+    from a file must not outlive the kernel it counted."""
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             doc = json.load(f)
     except (OSError, ValueError):
-        return None
-    if doc.get("csrc_sha16") != csrc_digest():
-        if name not in _stale_warned:
-            _stale_warned.add(name)
-            print("bench.py: profiles/%s was collected at kernel sources %s, running %s: its counters are reported as null "
-                  "(re-run tools/collect_profiles.sh)" % (name, doc.get("csrc_sha16"), csrc_digest()), file=sys.stderr, flush=True)
-        return None
-    return doc
+        return {}
+    if workload not in doc.get("workloads", {}):
+        return {}
+    stamp = doc.get("stamps", {}).get(workload, doc.get("csrc_sha16"))
+    if stamp != csrc_digest():
+        if (name, workload) not in _stale_warned:
+            _stale_warned.add((name, workload))
+            print("bench.py: profiles/%s [%s] was collected at kernel sources %s, running %s: its counters are reported as null "
+                  "(re-run tools/collect_profiles.sh)" % (name, workload, stamp, csrc_digest()), file=sys.stderr, flush=True)
+        return {}
+    return doc["workloads"][workload]
 
 
-def measured_traffic(workload, kernel_prefixes):
+def measured_traffic(workload, kernel_prefixes, per_frame=False):
     """HBM bytes per launch of the named kernel(s) from the committed rocprofv3 PMC summary (profiles/<round>_hbm_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH correction applied).  bench.py cannot run the profiler on itself,
-    so `traffic` is the last profiled value for this exact workload, or None."""
-    doc = committed_profile("%s_hbm_traffic.json" % ROUND)
-    w = (doc or {}).get("workloads", {}).get(workload, {})
-    tot = 0
-    for k, v in w.items():
-        if any(k.replace("mirt::", "").replace("void ", "").startswith(p) for p in kernel_prefixes):
-            tot += v["fetch_bytes"] + v["write_bytes"]
-    return tot or None
+    so `traffic` is the last profiled value for this exact workload, or None.  per_frame: the sum over the kernels of a FRAME --
+    those the pass saw more than twice (the per-scene table builders, the one-off light-cube build and torch's fills run once or
+    twice), each weighted by its launches per frame."""
+    w = committed_profile("%s_hbm_traffic.json" % ROUND, workload)
+    ks = {k: v for k, v in w.items() if any(k.replace("mirt::", "").replace("void ", "").startswith(p) for p in kernel_prefixes)}
+    if per_frame:
+        ks = {k: v for k, v in ks.items() if v.get("launches", 0) > 2}
+        most = max((v["launches"] for v in ks.values()), default=0)
+        tot = sum((v["fetch_bytes"] + v["write_bytes"]) * v["launches"] / most for v in ks.values()) if most else 0
+    else:
+        tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in ks.values())
+    return int(tot) or None
 
 
 def measured_valu_instructions(workload, kernel_prefix):
     """Wave-level VALU instructions per launch of the named kernel from the committed rocprofv3 PMC pass
     (profiles/<round>_pmc_issue.json: SQ_INSTS_VALU averaged over the launches), or None."""
-    doc = committed_profile("%s_pmc_issue.json" % ROUND)
-    for k, v in ((doc or {}).get("workloads", {}).get(workload, {})).items():
+    for k, v in committed_profile("%s_pmc_issue.json" % ROUND, workload).items():
         if kernel_prefix in k and "SQ_INSTS_VALU" in v:
             return float(v["SQ_INSTS_VALU"])
     return None
@@ -133,8 +147,7 @@ def measured_valu_instructions(workload, kernel_prefix):
 
 def measured_counter(workload, kernel_prefix, counter):
     """Any counter of the named kernel from the same committed pass (per launch), or None."""
-    doc = committed_profile("%s_pmc_issue.json" % ROUND)
-    for k, v in ((doc or {}).get("workloads", {}).get(workload, {})).items():
+    for k, v in committed_profile("%s_pmc_issue.json" % ROUND, workload).items():
         if kernel_prefix in k and counter in v:
             return float(v[counter])
     return None
@@ -156,8 +169,7 @@ def all_kinds_issue(workload, kernel_prefix, kernel_ms):
 def measured_valu_per_frame(workload):
     """VALU instructions of ALL per-frame kernels of the workload (every kernel the PMC pass saw more than twice: the
     per-scene table builders run once), per frame, from the same committed pass; or None."""
-    doc = committed_profile("%s_pmc_issue.json" % ROUND)
-    ks = (doc or {}).get("workloads", {}).get(workload, {})
+    ks = committed_profile("%s_pmc_issue.json" % ROUND, workload)
     per_frame = [v for v in ks.values() if "SQ_INSTS_VALU" in v and v.get("launches", 0) > 2]
     if not per_frame:
         return None
@@ -226,10 +238,7 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-            args.gpus = self.world
+        args.gpus = self.world                      # (main() has started the ranks itself when --gpus asked for more than the environment holds)
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
         # MIRT_BENCH_REHEARSAL=1: every rank on device 0 with a gloo group and host-staged gathers -- the N > 1 control
@@ -301,8 +310,9 @@ class Env:
         return [float(x) for x in t.tolist()]
 
 
-def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s=0.06, extras=True):
-    """Times `steps` steps of workload `name` and returns its result dict (rank 0; None elsewhere)."""
+def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s=0.06, extras=True, quick=False):
+    """Times `steps` steps of workload `name` and returns its result dict (rank 0; None elsewhere).  quick: a handful of frames
+    around the timed ones instead of dozens (frames that take a sixth of a second: the brute-force kernel on 100 k triangles)."""
     torch, dist, mirt = env.torch, env.dist, env.mirt
     from mirt.sharding import BandGather
     world, rank, dev = env.world, env.rank, env.dev
@@ -338,6 +348,11 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     # Every frame is still rendered, gathered and assembled inside the timed region.
     batch = 32 if (world > 1 and len(tris) < 1000 and kind == "rt") else 1
     native = getattr(env, "native", False)
+    # the library's own split: bands of equal estimated cost where the frame is binned (every rank derives them from the cost
+    # histogram of an earlier frame, nothing exchanged), equal rows otherwise
+    weighted = native and kind == "rt" and len(tris) >= 65 and os.environ.get("MIRT_BENCH_PARTITION", "weighted") == "weighted"
+    if world > 1:
+        mirt.set_partition(mirt.PARTITION_WEIGHTED if weighted else 0)
     bands = BandGather(H, W, dev, depth=depth, batch=1 if native else batch, via_host=env.rehearsal)
     y0, y1 = bands.y0, bands.y1
     mirt.set_frames_in_flight(in_flight)
@@ -426,8 +441,8 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
         return time.perf_counter() - t0
 
     # calibrate the batch: frames per step so that the timed region lasts >= target_s (agreed over the ranks)
-    timed(max(2 * batch, 12))                          # (also past the frames after which the light-cube grid settles: mirt_capi light_cache_ensure)
-    probe_frames = max(2 * batch, 8)
+    timed(2 if quick else max(2 * batch, 12))          # (also past the frames after which the light-cube grid settles: mirt_capi light_cache_ensure)
+    probe_frames = 2 if quick else max(2 * batch, 8)
     t_frame = timed(probe_frames) / probe_frames
     t_frame = env.reduce([t_frame], dist.ReduceOp.MAX)[0] if world > 1 else t_frame
     fps_step = max(1, int(np.ceil(target_s / (steps * max(t_frame, 1e-7)))))
@@ -475,8 +490,8 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     mirt.set_profiling(True)
     kacc, kn = {}, 0
     overlapped = in_flight >= 2 and not native and batch == 1
-    for i in range(max(4, min(steps * fps_step, 64) // 4)):
-        for _ in range(6 if overlapped else 1):
+    for i in range(1 if quick else max(4, min(steps * fps_step, 64) // 4)):
+        for _ in range((3 if quick else 6) if overlapped else 1):
             frame()
         if overlapped:
             kms, _ = mirt.previous_kernel_ms()
@@ -494,7 +509,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     kernel_ms_alone = None
     if overlapped:
         aacc, an = {}, 0
-        for i in range(12):
+        for i in range(2 if quick else 12):
             frame()
             mirt.sync()
             for k, v in mirt.stats()["kernel_ms"].items():
@@ -572,7 +587,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 "config": {"workload": name, "scene": "cornell-30" if scene[0] == "cornell" else "soup-%d-seed%d" % (scene[2], scene[1]),
                            "triangles": int(len(tris)), "width": W, "height": H, "lights": 1, "soft_shadow_samples": soft_samples, "aa_samples": aa, "dof_kernel": dof,
                            "primary_rays": W * H * aa * aa, "shadow_rays": int(shadow_frame), "mode": ["auto", "brute", "binned"][st["mode_used"]],
-                           "parallelism": ("bands%d+%s" % (world, "rccl-p2p-gather(libmirt)" if native else "torch-gather") + ("x%d" % batch if batch > 1 else "")) if world > 1 else "1gpu"},
+                           "parallelism": ("bands%d%s+%s" % (world, "(cost-weighted)" if weighted else "", "rccl-p2p-gather(libmirt)" if native else "torch-gather") + ("x%d" % batch if batch > 1 else "")) if world > 1 else "1gpu"},
             })
             kt = kernel_ms.get("trace", 0.0)
             kname = {mirt.RT_BRUTE: ("k_rt_tile<" if aa > 1 else "k_rt_tile2") if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
@@ -631,10 +646,10 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": round(algo_bytes / (kt * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS,
                                        "unit": "GB/s", "frac": round(algo_bytes / (kt * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                                        "traffic": measured_traffic(name, [kname]) if world == 1 else None,
-                                       "frame_traffic": measured_traffic(name, [""]) if world == 1 else None,
+                                       "frame_traffic": measured_traffic(name, [""], per_frame=True) if world == 1 else None,
                                        "algorithmic_bytes": int(algo_bytes),
                                        "note": "algorithmic bytes = 4*W*rows framebuffer + 60*N triangle list; far below the HBM roof by "
-                                               "construction; frame_traffic = every kernel of the frame"}
+                                               "construction; frame_traffic = every per-frame kernel (the PMC pass saw it more than twice), weighted by its launches per frame"}
         else:
             out.update({
                 "metric": "frames/s (rasteriser)", "unit": "frames/s", "dtype": "f32", "value": round(nframes / dt, 3),
@@ -689,7 +704,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 out["roofline_hbm"] = {"bound": "hbm", "achieved": round(algo_bytes / (tr * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                        "frac": round(algo_bytes / (tr * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                                        "traffic": measured_traffic(name, ["k_raster_small"]) if world == 1 else None,
-                                       "frame_traffic": measured_traffic(name, ["k_cull", "k_raster"]) if world == 1 else None,
+                                       "frame_traffic": measured_traffic(name, ["k_cull", "k_raster"], per_frame=True) if world == 1 else None,
                                        "algorithmic_bytes": int(algo_bytes),
                                        "note": "4 B per pixel written + the triangle list; no depth-key buffer on this path"}
             elif tr > 0:
@@ -742,6 +757,8 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     mirt.set_antialiasing(1)
     mirt.set_depth_of_field(0)
     mirt.set_frames_in_flight(1)
+    if world > 1:
+        mirt.set_partition(0)
     return out
 
 
@@ -851,16 +868,26 @@ def main():
     steps = args.steps if args.steps is not None else 20
     warmup = args.warmup if args.warmup is not None else 3
     name = args.workload or DEFAULT_WORKLOAD
-    target = 0.1 if args.mode != "brute" else 0.0
-    out = run_workload(env, name, steps, warmup, args.mode, not args.static_camera, not args.no_cpu_baseline, target_s=target)
+    # the timed region lasts a second at least (an activity sampler beside the run sees it); MIRT_BENCH_TARGET_S overrides
+    target = float(os.environ.get("MIRT_BENCH_TARGET_S", "1.0")) if args.mode != "brute" else 0.0
+    heavy_brute = args.mode == "brute" and WORKLOADS[name][1][0] == "soup"
+    out = run_workload(env, name, steps, warmup, args.mode, not args.static_camera, not args.no_cpu_baseline, target_s=target, quick=heavy_brute)
     if args.workload is None and not args.no_sub_results:
         subs = {}
+        keep = ("metric", "value", "unit", "ms_per_frame", "frames_per_s", "frames_per_step", "steps", "timed_region_s",
+                "kernel_ms_rank0", "kernel_ms_alone_rank0", "config", "roofline", "_cpu_leg")
         for sub in (SUB_RESULTS if env.world == 1 else SUB_RESULTS_SHARDED):
             # (no CPU leg for the 1 M-triangle frame: one 8K row of it is seconds of brute force on 64 cores)
-            r = run_workload(env, sub, max(4, steps // 2), 1, "auto", not args.static_camera, not args.no_cpu_baseline and sub != "soup1m8k", target_s=0.07, extras=False)
+            r = run_workload(env, sub, max(4, steps // 2), 1, "auto", not args.static_camera, not args.no_cpu_baseline and sub != "soup1m8k", target_s=min(target, 0.25), extras=False)
             if r is not None:
-                subs[sub] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_frame", "frames_per_s", "frames_per_step", "steps", "timed_region_s",
-                                               "kernel_ms_rank0", "kernel_ms_alone_rank0", "config", "roofline", "_cpu_leg") if k in r}
+                subs[sub] = {k: r[k] for k in keep if k in r}
+        if env.world == 1 and name == "soup100k" and args.mode != "brute":
+            # BASELINE configs[2] as worded -- "LDS-tiled brute-force intersect": ONE frame of the default workload through k_rt_brute
+            # (152 ms), the one kernel whose executed work IS the reference's rays x triangles x 60 flop, so its roofline fraction is
+            # the full-work one; the binned line above renders the same frame bit for bit in a 2 000th of the time
+            r = run_workload(env, "soup100k", 1, 0, "brute", not args.static_camera, False, target_s=0.0, extras=False, quick=True)
+            if r is not None:
+                subs["soup100k_brute"] = {k: r[k] for k in keep if k in r}
         if out is not None:
             out["sub_results"] = subs
     # the CPU legs, after all GPU timing

@@ -33,45 +33,47 @@ void band_of(int rank, int world, int height, int *y0, int *y1)
     *y1 = *y0 + base + (rank < rem ? 1 : 0);
 }
 
-int part_segments(int rank, int world, int height, int strip_rows)
+int part_segments(int rank, int world, int height, int strip_rows, const int *bounds)
 {
+    if (bounds) return bounds[rank + 1] > bounds[rank] ? 1 : 0;
     if (strip_rows <= 0) { int a, b; band_of(rank, world, height, &a, &b); return b > a ? 1 : 0; }
     const int strips = (height + strip_rows - 1) / strip_rows;
     return strips > rank ? (strips - rank + world - 1) / world : 0;
 }
 
-void part_segment(int rank, int world, int height, int strip_rows, int k, int *y0, int *y1)
+void part_segment(int rank, int world, int height, int strip_rows, int k, int *y0, int *y1, const int *bounds)
 {
+    if (bounds) { *y0 = bounds[rank]; *y1 = bounds[rank + 1]; return; }
     if (strip_rows <= 0) { band_of(rank, world, height, y0, y1); return; }
     const long long s = (long long)rank + (long long)k * world;       // the k-th strip of this rank
     *y0 = (int)std::min<long long>(s * strip_rows, height);
     *y1 = (int)std::min<long long>((s + 1) * strip_rows, height);
 }
 
-int part_rows(int rank, int world, int height, int strip_rows)
+int part_rows(int rank, int world, int height, int strip_rows, const int *bounds)
 {
     int rows = 0;
-    for (int k = 0, n = part_segments(rank, world, height, strip_rows); k < n; k++) {
+    for (int k = 0, n = part_segments(rank, world, height, strip_rows, bounds); k < n; k++) {
         int a, b;
-        part_segment(rank, world, height, strip_rows, k, &a, &b);
+        part_segment(rank, world, height, strip_rows, k, &a, &b, bounds);
         rows += b - a;
     }
     return rows;
 }
 
-int part_gather_plan(int world, int root, int width, int height, int nviews, int strip_rows, BandPiece *out, int max_pieces)
+int part_gather_plan(int world, int root, int width, int height, int nviews, int strip_rows, BandPiece *out, int max_pieces, const int *bounds)
 {
     const size_t row = (size_t)width * 4, frame = (size_t)height * row;
     int n = 0;
     for (int r = 0; r < world; r++) {
         if (r == root) continue;
-        const int segs = part_segments(r, world, height, strip_rows);
-        const size_t mine = (size_t)part_rows(r, world, height, strip_rows) * row;      // this rank's rows of ONE view in its band buffer
+        const int segs = part_segments(r, world, height, strip_rows, bounds);
+        const size_t mine = (size_t)part_rows(r, world, height, strip_rows, bounds) * row;      // this rank's rows of ONE view in its band buffer
         for (int v = 0; v < nviews; v++) {
             size_t before = 0;
             for (int k = 0; k < segs; k++) {
                 int a, b;
-                part_segment(r, world, height, strip_rows, k, &a, &b);
+                part_segment(r, world, height, strip_rows, k, &a, &b, bounds);
                 const size_t bytes = (size_t)(b - a) * row;
                 if (bytes == 0) continue;
                 if (n < max_pieces) out[n] = { (size_t)v * frame + (size_t)a * row, (size_t)v * mine + before, bytes, r };
@@ -81,6 +83,49 @@ int part_gather_plan(int world, int root, int width, int height, int nviews, int
         }
     }
     return n;
+}
+
+// Bands of equal ESTIMATED COST (the repo's counterpart of the reference's `#pragma omp parallel for schedule(auto)` over rows,
+// raytracer.cpp:557: rows go where the work is).  hist[c] = estimated (tile, triangle) pairs of coarse tile row c (tile rows
+// c << shift .. ((c + 1) << shift) - 1) of the whole frame, as k_prep_select counts them; a tile row's cost = its share of its
+// coarse row's pairs + tile_weight per tile (the work a pixel costs whatever its tile's list holds: ray set-up, shading, the
+// shadow ray, the store).  Boundaries fall on tile rows (8 pixel rows), rank r gets the tile rows whose running cost lies in
+// [r, r + 1) * total / world, every rank at least one tile row while there are enough.  Integer arithmetic only: every rank of
+// a group computes the same boundaries from the same histogram.  bounds: world + 1 rows, bounds[0] = 0, bounds[world] = height.
+void part_weighted_bounds(const uint32_t *hist, int hist_rows, int shift, int width, int height, int world, unsigned tile_weight, int *bounds)
+{
+    const int tile = 8, tile_rows = (height + tile - 1) / tile, tiles_x = (width + tile - 1) / tile;
+    std::vector<unsigned long long> cost((size_t)std::max(tile_rows, 1), 0ull);
+    for (int j = 0; j < tile_rows; j++) {
+        const int c = j >> shift;
+        const int first = c << shift, last = std::min(tile_rows, (c + 1) << shift);      // the coarse row's tile rows
+        const unsigned long long h = (hist && c < hist_rows) ? hist[c] : 0ull;
+        cost[(size_t)j] = h / (unsigned long long)std::max(last - first, 1) + (unsigned long long)tile_weight * (unsigned long long)tiles_x + 1ull;
+    }
+    // prefix[j] = cost of tile rows [0, j)
+    std::vector<unsigned long long> prefix((size_t)tile_rows + 1, 0ull);
+    for (int j = 0; j < tile_rows; j++) prefix[(size_t)j + 1] = prefix[(size_t)j] + cost[(size_t)j];
+    const unsigned long long total = prefix[(size_t)tile_rows];
+    bounds[0] = 0;
+    int j = 0;
+    for (int r = 1; r < world; r++) {
+        // the cut (in tile rows) whose running cost is nearest to r / world of the total (compared as prefix * world vs total * r:
+        // 128-bit products, no division, no rounding)
+        const unsigned __int128 want = (unsigned __int128)total * (unsigned)r;
+        while (j < tile_rows && (unsigned __int128)prefix[(size_t)j + 1] * (unsigned)world <= want) j++;
+        int cut = j;
+        if (j < tile_rows) {
+            const unsigned __int128 lo = (unsigned __int128)prefix[(size_t)j] * (unsigned)world, hi = (unsigned __int128)prefix[(size_t)j + 1] * (unsigned)world;
+            if (hi - want < want - lo) cut = j + 1;
+        }
+        // every rank keeps at least one tile row while the frame has enough of them
+        const int prev = (bounds[r - 1] + tile - 1) / tile;
+        if (tile_rows >= world) cut = std::min(std::max(cut, prev + 1), tile_rows - (world - r));
+        cut = std::max(cut, prev);
+        bounds[r] = std::min(cut * tile, height);
+    }
+    bounds[world] = height;
+    for (int r = 1; r <= world; r++) bounds[r] = std::max(bounds[r], bounds[r - 1]);
 }
 
 int band_gather_plan(int world, int root, int width, int height, int nviews, BandPiece *out, int max_pieces)

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <cstdint>
 
 namespace mirt {
 
@@ -18,9 +19,13 @@ void band_of(int rank, int world, int height, int *y0, int *y1);
 //                     frame, which evens out scenes whose cost is concentrated in some rows (the reference's schedule(auto) over
 //                     rows, raytracer.cpp:557, at the granularity a GPU launch needs).
 // A rank's band buffer holds its segments of one view back to back, views one after the other.
-int part_segments(int rank, int world, int height, int strip_rows);                          // how many segments the rank has
-void part_segment(int rank, int world, int height, int strip_rows, int k, int *y0, int *y1);  // its k-th: rows [y0, y1)
-int part_rows(int rank, int world, int height, int strip_rows);                              // its rows in total
+//   bounds != NULL    contiguous bands with explicit boundaries: rank r renders rows [bounds[r], bounds[r + 1]) -- the weighted
+//                     partition (part_weighted_bounds), bands of equal estimated cost; strip_rows is ignored.
+int part_segments(int rank, int world, int height, int strip_rows, const int *bounds = nullptr);                          // how many segments the rank has
+void part_segment(int rank, int world, int height, int strip_rows, int k, int *y0, int *y1, const int *bounds = nullptr);  // its k-th: rows [y0, y1)
+int part_rows(int rank, int world, int height, int strip_rows, const int *bounds = nullptr);                              // its rows in total
+// world + 1 boundaries (multiples of 8 rows) of bands of equal estimated cost; pure integer arithmetic (comm.cpp)
+void part_weighted_bounds(const uint32_t *hist, int hist_rows, int shift, int width, int height, int world, unsigned tile_weight, int *bounds);
 
 struct Comm;
 // rank 0 creates the id (ncclGetUniqueId; a file-name prefix for the shm transport) and hands it to the other ranks
@@ -37,7 +42,7 @@ int comm_world(const Comm *c);
 struct BandPiece { size_t root_offset, band_offset, bytes; int peer; };
 int band_gather_plan(int world, int root, int width, int height, int nviews, BandPiece *out, int max_pieces);
 // ... for either partition: one piece per (rank, view, segment)
-int part_gather_plan(int world, int root, int width, int height, int nviews, int strip_rows, BandPiece *out, int max_pieces);
+int part_gather_plan(int world, int root, int width, int height, int nviews, int strip_rows, BandPiece *out, int max_pieces, const int *bounds = nullptr);
 
 // One message of the gather.  On the root: `bytes` from rank `peer` land at `ptr`; elsewhere: `bytes` at `ptr` go to the root.
 struct GatherPiece { void *ptr; size_t bytes; int peer; };

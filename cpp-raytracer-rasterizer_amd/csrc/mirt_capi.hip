@@ -57,14 +57,17 @@ struct RtTraceFrame {                            // (rt_trace.hip)
     const TilePairRec *order;
     const uint32_t *order_count;
     uint32_t order_seg;
+    const uint32_t *sel;
+    const uint32_t *sel_count;
 };
 template <bool AA> __global__ void k_rt_trace2(const RtTraceFrame);
+__global__ void k_prep_select(const float *, int, const BinFrameDesc, const SelectOut);
 __global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *, uint32_t);
 __global__ void k_geo_table(const float *, int, GeoRow *, ShadeRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t,
                                     const float *, const float *, uint32_t *);
 size_t rt_trace_lds_bytes(int waves);
-int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev);
+int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev, bool *ev_used);
 __global__ void k_cull(const float *, int, const CullParams, uint8_t *);
 
 namespace {
@@ -113,6 +116,14 @@ hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t st
     return hipGetLastError();
 }
 
+// The cost histogram of a pass leaves the device behind k_prep_select: its words go to a pinned copy the host reads later
+// (weighted partition), and the device words are zero again for the next pass.
+__global__ __launch_bounds__(SEL_HIST_MAX) void k_hist_out(uint32_t *__restrict__ hist, uint32_t *__restrict__ host_copy)
+{
+    host_copy[threadIdx.x] = hist[threadIdx.x];
+    hist[threadIdx.x] = 0u;
+}
+
 struct RtScratch {
     OriginRow *d_cam_tab = nullptr;              // n rows (cam_tab_n)
     OriginRow *d_light_tab = nullptr;            // light_tab_lights x n rows
@@ -149,7 +160,22 @@ struct RtScratch {
     uint32_t cap_order = 0;
     int last_bin_mode = -1;                      // what the last pass binned (camera alone / camera + n light cubes): a guessed
                                                  // list size only carries over between passes of the same kind
+    // k_prep_select: the triangles the frame may see (indices, sel_n slots) and the two counters its passes use in turn (the pass
+    // that counts into one zeroes the other: d_bin_counters[SEL_COUNT0 + parity])
+    uint32_t *d_sel = nullptr;
+    int sel_n = 0;
+    int sel_parity = 0;
+    // the cost histogram of the whole frame (weighted partition): device words, and where they travel for the host to read --
+    // HIST_RING pinned copies taken in turn, an event behind each
+    uint32_t *d_hist = nullptr;
+    uint32_t *h_hist = nullptr;                  // pinned: HIST_RING x SEL_HIST_MAX words
+    hipEvent_t ev_hist[4] = {};
+    uint64_t hist_key[4] = {};                   // what frame (view, scene) each copy belongs to; 0 = none
+    int hist_rows[4] = {}, hist_shift[4] = {};
+    int hist_next = 0;
 };
+constexpr int SEL_COUNT0 = 80;                   // word of d_bin_counters where the two selection counters start
+constexpr int HIST_RING = 4;
 
 // The light-cube bins of the binned ray tracer: they depend on the scene and the light positions only, not on the camera,
 // so they are built once per (scene version, light positions, grid) and shared by the frames of both streams.
@@ -251,7 +277,12 @@ struct Ctx {
     char *d_band[2] = { nullptr, nullptr };
     size_t band_bytes[2] = { 0, 0 };
     int band_slot = 0;
-    int strip_rows = 0;                          // partition of a sharded frame: 0 = contiguous bands, > 0 = interleaved strips of that many rows (mirt_set_partition)
+    int strip_rows = 0;                          // partition of a sharded frame: 0 = contiguous bands, > 0 = interleaved strips of that many rows,
+                                                 // MIRT_PARTITION_WEIGHTED = bands of equal estimated cost (mirt_set_partition)
+    bool want_hist = false;                      // binned ray-traced frames leave their cost histogram (mirt_set_cost_histogram, or the weighted partition)
+    uint64_t shard_calls = 0;                    // sharded calls so far: what a cost histogram is filed under
+    bool hist_taken = false;                     // the current sharded call has filed its histogram (the first binned pass of a call does)
+    bool in_sharded = false;
 
     // statistics of the last call
     mirt_stats stats = {};
@@ -264,6 +295,7 @@ struct Ctx {
     bool pending_is_rt = false;
     bool pending_counted = false;                // the kernel counted its executed tests itself (tile / binned)
     bool pending_empty = false;                  // the last ray-trace call rendered no rows (no counters to read)
+    const uint32_t *stats_sel_count = nullptr;   // binned frame that ran a pass: where its selection count is (device)
 };
 
 Ctx g;
@@ -354,6 +386,7 @@ void call_begin()
     (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (torch polls events:
                                                  // hipErrorNotReady) so that the launch checks below report our own launches only
     memset(&g.stats, 0, sizeof g.stats);
+    g.stats_sel_count = nullptr;
     g.ev_cur = g.si;
     g.ev = g.ev_sets[g.ev_cur];
     g.ev_used = g.ev_used_sets[g.ev_cur];
@@ -435,6 +468,15 @@ int ensure_pairs(RtScratch &S, size_t cap)
 // bucket of at most 1024 keys (bin_bucket_sort.hip).  The callers choose their grids and shell counts to stay below it.
 constexpr uint32_t BIN_MAX_KEYS = BUCKET_SORT_MAX_BUCKETS * 1024u - 1u;
 
+// Picks up the pair count an earlier frame of the stream has published (pinned word + event), if it has landed.
+void poll_pair_count(RtScratch &S)
+{
+    if (S.count_pending && hipEventQuery(S.ev_count) == hipSuccess) {
+        S.known_pairs = *S.h_count; S.have_known = true; S.count_pending = false;
+    }
+    (void)hipGetLastError();                                 // (hipErrorNotReady of the query is not an error)
+}
+
 // One binning pass on g.stream: (key, triangle) pairs of `bs`' frames into S' pair list, ordered by key into S.d_entries /
 // S.d_sorted_keys, offsets into bin_off.  `counter` (device, zeroed by the caller's previous kernel) receives the pair
 // count.  The list is sized from a count only the device knows: when `fresh` it is read back (4 bytes + one sync of this
@@ -445,11 +487,7 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
              bool fresh, uint32_t *npairs, bool may_guess = false)
 {
     int rc;
-    // a count an earlier frame left behind?
-    if (S.count_pending && hipEventQuery(S.ev_count) == hipSuccess) {
-        S.known_pairs = *S.h_count; S.have_known = true; S.count_pending = false;
-    }
-    (void)hipGetLastError();                                 // (hipErrorNotReady of the query is not an error)
+    poll_pair_count(S);                                      // a count an earlier frame left behind?
     // A pass identical to the one before it (same view, same scene) normally reuses that pass's count without looking; but if
     // that pass was itself a guess and its published count shows the list was too small, the frame fell back to brute force
     // and so would every later frame of this view: treat it as fresh again so that the list grows.
@@ -708,10 +746,55 @@ bool frame_fits_binning(int W, int H)
 // needs no barrier between the streams and no host sync (the list is sized like the camera's: from an earlier frame's count).
 // The reference moves the light with keys as readily as the camera (raytracer.cpp:152-162).
 constexpr int LIGHT_STABLE_FRAMES = 4;
+
+// The cost histogram (k_prep_select): wanted when the caller asked for it or the partition is the weighted one, and then from ONE
+// pass per sharded call -- the first -- so that every rank files the same sequence.  hist_prepare points the pass at the device
+// words (zero between passes: k_hist_out leaves them so); hist_publish sends them to the next pinned copy of the ring, tagged
+// with the sharded call they belong to, an event behind them.
+bool hist_wanted() { return (g.want_hist || g.strip_rows == MIRT_PARTITION_WEIGHTED) && !(g.in_sharded && g.hist_taken); }
+int hist_shift_for(int tile_rows) { int sh = 0; while (((tile_rows - 1) >> sh) + 1 > SEL_HIST_MAX) sh++; return sh; }
+bool g_hist_armed = false;                       // hist_prepare armed the pass that is being enqueued
+int hist_prepare(RtScratch &S, const BinFrameDesc &cam, uint64_t key, SelectOut *so)
+{
+    g_hist_armed = false;
+    if (!hist_wanted()) return MIRT_OK;
+    if (!S.d_hist) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_hist), sizeof(uint32_t) * SEL_HIST_MAX));
+        HIP_TRY(hipMemsetAsync(S.d_hist, 0, sizeof(uint32_t) * SEL_HIST_MAX, g.stream));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.h_hist), sizeof(uint32_t) * SEL_HIST_MAX * HIST_RING, hipHostMallocDefault));
+        for (int i = 0; i < HIST_RING; i++) HIP_TRY(hipEventCreateWithFlags(&S.ev_hist[i], hipEventDisableTiming));
+    }
+    so->hist = S.d_hist;
+    so->hist_shift = hist_shift_for(cam.nbv);
+    const int slot = S.hist_next;
+    // (the copy about to be overwritten was filed HIST_RING passes ago; a reader only ever looks at copies whose event has fired)
+    S.hist_key[slot] = 0;
+    S.hist_rows[slot] = ((cam.nbv - 1) >> so->hist_shift) + 1;
+    S.hist_shift[slot] = so->hist_shift;
+    (void)key;
+    g_hist_armed = true;
+    return MIRT_OK;
+}
+int hist_publish(RtScratch &S)
+{
+    if (!g_hist_armed) return MIRT_OK;
+    g_hist_armed = false;
+    const int slot = S.hist_next;
+    uint32_t *dst = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&dst), S.h_hist + (size_t)slot * SEL_HIST_MAX, 0));
+    hipLaunchKernelGGL(k_hist_out, dim3(1), dim3(SEL_HIST_MAX), 0, g.stream, S.d_hist, dst);
+    HIP_TRY(hipEventRecord(S.ev_hist[slot], g.stream));
+    S.hist_key[slot] = g.shard_calls + 1;        // filed under the sharded call in progress (+1: 0 means "no copy"); outside one, the calls so far
+    S.hist_next = (slot + 1) % HIST_RING;
+    if (g.in_sharded) g.hist_taken = true;
+    return MIRT_OK;
+}
+
 int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const float *origins, int nlights, int y0, int y1)
 {
     int rc;
     g.stats.mode_used = MIRT_RT_BINNED;
+    g.stats_sel_count = nullptr;
     // light-cube resolution: bins per face side.  Finer grids shorten the shadow lists; the shared bins are built once per
     // (scene, lights), not per frame, so what they cost is memory (48 bytes per (bin, triangle) pair) and ~1 ms of build for
     // 100 k triangles.  Measured on the 100 k soup at 1080p (round 2's trace kernel, lists not yet ordered by depth): 64: 153 us,
@@ -737,17 +820,26 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     memset(&bs, 0, sizeof bs);
     bs.frame0 = make_camera_frame(view, y0, y1, g.aa);
     bs.frames = nullptr; bs.nframes = 1;
+    // The camera's sort keys are LOCAL to the rows the call renders: tile (i, j) of a band that starts at tile row j0 has bin
+    // (j - j0) * nbu + i (the frame's `base` is -j0 * nbu, modulo 2^32), so a band of a sharded frame sorts an eighth of the keys
+    // -- buckets an eighth as wide, spread over all the sort's workgroups -- and writes an eighth of the offsets.  (With the whole
+    // frame's key space a band's pairs sat in an eighth of the buckets: k_bs_local took 94 us for a middle band of the 1 M-triangle
+    // frame at 8K against 112 us for the whole frame.)  The kernels that index the offsets by the frame's tile number get the
+    // array's base shifted accordingly (cam_off below).
+    const int band_tile_rows = bs.frame0.j1 - bs.frame0.j0;
+    const uint32_t key_shift_tiles = (uint32_t)bs.frame0.j0 * (uint32_t)bs.frame0.nbu;
+    bs.frame0.base = 0u - key_shift_tiles;
     {
         // depth shells: the tiles' lists come out of the sort roughly front to back (key = bin * shells + shell of the
         // candidate's `near` bound, uniform steps between the nearest and the farthest point of the scene's box)
-        const int ns = camera_shells_for((long long)bs.frame0.nbu * bs.frame0.nbv);
+        const int ns = camera_shells_for((long long)bs.frame0.nbu * band_tile_rows);
         double dn = 0.0, df = 0.0;
         const bool okr = shell_range(view->pos, &dn, &df);
         bs.frame0.nshell = okr ? ns : 1;
         bs.frame0.shell_d0 = (float)dn;
         bs.frame0.shell_iw = okr ? (float)(ns / (df - dn)) : 0.0f;
     }
-    const uint32_t cam_keys = (uint32_t)bs.frame0.nbu * bs.frame0.nbv * (uint32_t)bs.frame0.nshell;
+    const uint32_t cam_keys = (uint32_t)bs.frame0.nbu * (uint32_t)band_tile_rows * (uint32_t)bs.frame0.nshell;
     // this frame's own light cubes (moving lights): their keys follow the camera's, from a multiple of their shell count on
     const int tshells = transient ? light_shells_for(nlights, cube_bins, cam_keys) : 1;
     const uint32_t light_key0 = transient ? (cam_keys + (uint32_t)tshells - 1u) / (uint32_t)tshells * (uint32_t)tshells : cam_keys;
@@ -755,6 +847,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     bs.nbins = transient ? light_key0 + per_light * (uint32_t)nlights : cam_keys;
     if (bs.nbins + 1 > S.cap_bins) {
         const size_t cap = (size_t)bs.nbins + 1;
+        HIP_TRY(hipStreamSynchronize(g.stream));             // (a frame of this stream may still read the old array)
         if ((rc = dev_realloc(&S.d_bin_off, cap))) { S.cap_bins = 0; return rc; }
         S.cap_bins = (uint32_t)cap;
         S.bin_key_valid = false;
@@ -764,6 +857,13 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     // to land AFTER the first kernels of g.stream had started counting, which cut the pair count short (a light cube built from
     // it kept wrong shadows until the lights moved; a camera pass failed with "produced N pairs twice").
     if (!S.d_bin_counters) { HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), 512)); HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, 512, g.stream)); }
+    if (S.sel_n != g.n) {
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        S.sel_n = 0;
+        if ((rc = dev_realloc(&S.d_sel, (size_t)g.n))) return rc;
+        S.sel_n = g.n;
+        S.bin_key_valid = false;
+    }
     bs.bin_off = S.d_bin_off;
 
     uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
@@ -775,65 +875,91 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     const int bin_mode = transient ? 1 + nlights : 0;
     g.hits_clean[g.hits_cur] = false;
     if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * (1 + 6 * MIRT_MAX_LIGHTS)));
-    if (transient) {
-        // this stream's own light tables: origin rows per light, the cubes' frame descriptors behind the camera's, the rows
-        if (nlights > S.light_tab_lights || S.light_tab_n != g.n) {
-            HIP_TRY(hipStreamSynchronize(g.stream));
-            S.light_tab_lights = 0;
-            if ((rc = dev_realloc(&S.d_light_tab, (size_t)nlights * g.n))) return rc;
-            S.light_tab_lights = nlights;
-            S.light_tab_n = g.n;
-        }
-        BinFrameDesc frames[1 + 6 * MIRT_MAX_LIGHTS];
-        frames[0] = bs.frame0;
-        fill_light_frames(frames + 1, f, nlights, cube_bins, tshells, light_key0 / (uint32_t)tshells);
-        HIP_TRY(upload_small(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), g.stream));
-        HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
-        bs.frames = S.d_frames; bs.nframes = 1 + 6 * nlights;
-        // first kernel of the frame: origin rows of the camera and of every light; it also zeroes the hit and pair counters
-        hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1 + nlights), dim3(256), 0, g.stream,
-                           g.d_tris, g.n, S.d_origins, V3(0.0f, 0.0f, 0.0f), 0, S.d_cam_tab, S.d_light_tab,
-                           (uint32_t *)nullptr, g.d_hits, S.d_bin_counters);
-    } else {
-        // first kernel of the frame: the camera's origin rows; it also zeroes the hit counters and the pair counter
-        hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, 1), dim3(256), 0, g.stream,
-                           g.d_tris, g.n, (const float *)nullptr, V3(origins[0], origins[1], origins[2]), 0, S.d_cam_tab, (OriginRow *)nullptr,
-                           (uint32_t *)nullptr, g.d_hits, S.d_bin_counters);
-    }
-    // the pair count is read back (4 bytes + one sync of this stream) only when the inputs that determine it changed AND no
-    // count of an earlier pass of the same kind is at hand (a camera-only count says nothing about camera + light cubes)
-    const bool fresh = !S.bin_key_valid || S.bin_key != key;
+    // The pair count is read back (4 bytes + one sync of this stream) only when the inputs that determine it changed AND no
+    // count of an earlier pass of the same kind is at hand (a camera-only count says nothing about camera + light cubes).
+    // When NOTHING the pass depends on has changed since this stream's last pass -- the view stands still while a light key, a
+    // toggle or nothing at all asks for a frame (raytracer.cpp:385-537 set isUpdated without touching cameraPos / yaw) -- the
+    // stream still holds that pass's tables: origin rows, selection, sorted lists, offsets, tile order, and with them the rows
+    // of lights binned by the frame.  The frame then starts at the trace kernel.  (A kept pass whose list turned out too small
+    // -- its published count says so -- is redone, so that the list grows: bin_pass.)
+    poll_pair_count(S);
+    bool fresh = !S.bin_key_valid || S.bin_key != key;
     const bool may_guess = S.last_bin_mode == bin_mode;
-    if ((rc = bin_pass(S, bs, S.d_cam_tab, transient ? S.d_light_tab : nullptr, S.d_bin_counters, S.d_bin_off, fresh, &S.bin_entries, may_guess))) return rc;
-    S.last_bin_mode = bin_mode;
-    S.bin_key = key;
-    S.bin_key_valid = true;
-    if (transient) {
-        if (S.cap_light_rows < S.cap_entries) {              // one row per pair at most; grown with the pair list (rare)
-            HIP_TRY(hipStreamSynchronize(g.stream));
-            S.cap_light_rows = 0;
-            if ((rc = dev_realloc(&S.d_light_rows, (size_t)S.cap_entries))) return rc;
-            S.cap_light_rows = S.cap_entries;
-        }
-        const uint32_t expect = std::max<uint32_t>(S.bin_entries, 1u);
-        hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                           S.d_bin_off + light_key0, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used,
-                           g.d_tris, S.d_origins, (uint32_t *)nullptr);
-    }
-    // the order the trace kernel's waves take the tile pairs in: per XCD group (pairs of tile rows dealt round-robin), longest
-    // lists first
+    if (!fresh && S.have_known && S.known_pairs > S.cap_used) fresh = true;
+    static const bool reuse_off = [] { const char *e = getenv("MIRT_BIN_REUSE"); return e && atoi(e) == 0; }();
+    const bool reuse = !fresh && !reuse_off;
     const uint32_t pairs_x = (uint32_t)((bs.frame0.nbu + 1) / 2);
     uint32_t group_rows[ORDER_GROUPS] = { 0 };
     for (int j = bs.frame0.j0; j < bs.frame0.j1; j++) group_rows[((uint32_t)j >> ORDER_STRIPE_SHIFT) & (ORDER_GROUPS - 1)]++;
     const uint32_t order_seg = pairs_x * *std::max_element(group_rows, group_rows + ORDER_GROUPS);
-    if ((size_t)order_seg > S.cap_order) {
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        S.cap_order = 0;
-        if ((rc = dev_realloc(&S.d_order, (size_t)ORDER_GROUPS * ORDER_CLASSES * order_seg))) return rc;
-        S.cap_order = order_seg;
+    const uint32_t *cam_off = S.d_bin_off - (size_t)key_shift_tiles * (size_t)bs.frame0.nshell;   // indexed by the FRAME's tile number
+    if (reuse) {
+        // (the first kernel of a pass zeroes the frame's hit counters on the way; here nothing runs in front of the trace kernel)
+        HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
+        g.stats.bins_reused = 1;
+    } else {
+        // first kernel of the frame: the camera's origin rows for the triangles the rows of this call can see, and their list
+        // (k_prep_select); it also zeroes the hit counters and the pass's counters
+        S.sel_parity ^= 1;
+        SelectOut so;
+        memset(&so, 0, sizeof so);
+        so.cam_tab = S.d_cam_tab; so.sel = S.d_sel;
+        so.sel_count = S.d_bin_counters + SEL_COUNT0 + S.sel_parity; so.sel_count_next = S.d_bin_counters + SEL_COUNT0 + (S.sel_parity ^ 1);
+        so.zero_hits = g.d_hits; so.zero_counter = S.d_bin_counters;
+        if ((rc = hist_prepare(S, bs.frame0, key, &so))) return rc;
+        // one workgroup of 1024 threads per CU: a workgroup reserves its slice of the list with ONE atomic (rt_binned.hip)
+        const unsigned sel_grid = (unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count);
+        hipLaunchKernelGGL(k_prep_select, dim3(sel_grid), dim3(1024), 0, g.stream, g.d_tris, g.n, bs.frame0, so);
+        if ((rc = hist_publish(S))) return rc;
+        bs.sel = S.d_sel; bs.sel_count = so.sel_count;
+        g.stats_sel_count = so.sel_count;
+        if (transient) {
+            // this stream's own light tables: origin rows per light, the cubes' frame descriptors behind the camera's, the rows
+            if (nlights > S.light_tab_lights || S.light_tab_n != g.n) {
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                S.light_tab_lights = 0;
+                if ((rc = dev_realloc(&S.d_light_tab, (size_t)nlights * g.n))) return rc;
+                S.light_tab_lights = nlights;
+                S.light_tab_n = g.n;
+            }
+            BinFrameDesc frames[1 + 6 * MIRT_MAX_LIGHTS];
+            frames[0] = bs.frame0;
+            fill_light_frames(frames + 1, f, nlights, cube_bins, tshells, light_key0 / (uint32_t)tshells);
+            HIP_TRY(upload_small(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), g.stream));
+            HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
+            bs.frames = S.d_frames; bs.nframes = 1 + 6 * nlights;
+            // origin rows of every light (all triangles: a light cube sees the whole scene)
+            hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, nlights), dim3(256), 0, g.stream,
+                               g.d_tris, g.n, S.d_origins, V3(0.0f, 0.0f, 0.0f), 1, (OriginRow *)nullptr, S.d_light_tab,
+                               (uint32_t *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr);
+        }
+        if ((rc = bin_pass(S, bs, S.d_cam_tab, transient ? S.d_light_tab : nullptr, S.d_bin_counters, S.d_bin_off, true, &S.bin_entries, may_guess))) return rc;
+        S.last_bin_mode = bin_mode;
+        S.bin_key = key;
+        S.bin_key_valid = true;
+        if (transient) {
+            if (S.cap_light_rows < S.cap_entries) {              // one row per pair at most; grown with the pair list (rare)
+                HIP_TRY(hipStreamSynchronize(g.stream));
+                S.cap_light_rows = 0;
+                if ((rc = dev_realloc(&S.d_light_rows, (size_t)S.cap_entries))) return rc;
+                S.cap_light_rows = S.cap_entries;
+            }
+            const uint32_t expect = std::max<uint32_t>(S.bin_entries, 1u);
+            hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
+                               S.d_bin_off + light_key0, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used,
+                               g.d_tris, S.d_origins, (uint32_t *)nullptr);
+        }
+        // the order the trace kernel's waves take the tile pairs in: per XCD group (pairs of tile rows dealt round-robin), longest
+        // lists first
+        if ((size_t)order_seg > S.cap_order) {
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            S.cap_order = 0;
+            if ((rc = dev_realloc(&S.d_order, (size_t)ORDER_GROUPS * ORDER_CLASSES * order_seg))) return rc;
+            S.cap_order = order_seg;
+        }
+        hipLaunchKernelGGL(k_tile_order, dim3((pairs_x + 63) / 64, (unsigned)(bs.frame0.j1 - bs.frame0.j0)), dim3(64), 0, g.stream, cam_off, bs.frame0.nshell,
+                           bs.frame0.nbu, bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order, order_seg);
     }
-    hipLaunchKernelGGL(k_tile_order, dim3((pairs_x + 63) / 64, (unsigned)(bs.frame0.j1 - bs.frame0.j0)), dim3(64), 0, g.stream, S.d_bin_off, bs.frame0.nshell,
-                       bs.frame0.nbu, bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order, order_seg);
     k_end(MIRT_K_BIN);
 
     RtTraceFrame tf;
@@ -843,8 +969,9 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     // (a frame whose pair list overflowed walks the origin tables themselves: every triangle for every ray)
     tf.f.light_tab = transient ? S.d_light_tab : g.lc.d_light_tab;
     tf.f.unsafe = nullptr;
-    tf.cam_off = S.d_bin_off;
+    tf.cam_off = cam_off;
     tf.cam_entries = S.d_entries;
+    tf.sel = S.d_sel; tf.sel_count = S.d_bin_counters + SEL_COUNT0 + S.sel_parity;
     tf.geo = g.d_geo;
     tf.shade = g.d_shade;
     tf.light_off = transient ? S.d_bin_off + light_key0 : g.lc.d_off;
@@ -1055,6 +1182,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
     if (binned) return rt_enqueue_binned(f, view, S, origins, nlights, y0, y1);
 
     HIP_TRY(upload_small(S.d_flags, flags_init, sizeof flags_init, g.stream));
+    S.bin_key_valid = false;                     // (k_prep_origin below overwrites the camera rows a kept binning pass would count on)
     g.hits_clean[g.hits_cur] = false;
     HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
 
@@ -1235,6 +1363,12 @@ extern "C" void mirt_shutdown(void)
                          (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, (void *)S.d_tmp_vals, (void *)S.d_bucket })
             if (p) (void)hipFree(p);
     for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }
+    for (RtScratch &S : g.rt) {
+        if (S.d_sel) (void)hipFree(S.d_sel);
+        if (S.d_hist) (void)hipFree(S.d_hist);
+        if (S.h_hist) (void)hipHostFree(S.h_hist);
+        for (hipEvent_t e : S.ev_hist) if (e) (void)hipEventDestroy(e);
+    }
     for (void *p : { (void *)g.d_geo, (void *)g.d_shade, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_row_tri, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
         if (p) (void)hipFree(p);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos })
@@ -1358,6 +1492,7 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
     if ((rc = dev_realloc(&g.d_culled, (size_t)MAX_FLIGHT * n))) return rc;
     for (RtScratch &S : g.rt) { S.bin_key_valid = false; S.have_known = false; S.count_pending = false; }   // tables and pair counts belong to the old scene
+    for (RtScratch &S : g.rt) for (uint64_t &k : S.hist_key) k = 0;                                          // ... and so do the cost histograms
     HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
     g.cull_calls++;
     for (int h = 0; h < MAX_FLIGHT; h++) {
@@ -1406,6 +1541,22 @@ extern "C" int mirt_scene_set_culled(const uint8_t *culled, int n)
     return MIRT_OK;
 }
 
+// Orders a WRITE into cull-flag copy `dst`, about to be queued on stream `st`, behind every copy OUT of it that another stream
+// still has pending (a rasterised frame that brought the latest flags over to its own copy): a bit per copy and stream says
+// which streams have read `dst` since the last writer waited; a stream's event is re-recorded behind each of its reads, and a
+// stream runs in order, so waiting for its latest record covers the earlier ones.  Both writers come here: the cull kernel
+// (mirt_cull_device) and the hand-over copy of raster_enqueue -- with three or four frames in flight the latter can overwrite a
+// copy that a lagging stream is still reading (advisor finding of round 3).
+static int cull_copy_wait_readers(int dst, hipStream_t st)
+{
+    for (int r = 0; r < MAX_FLIGHT; r++)
+        if ((g.cull_read_src[r] >> dst & 1u) && r != dst) {
+            HIP_TRY(hipStreamWaitEvent(st, g.ev_cull_read[r], 0));
+            g.cull_read_src[r] &= ~(1u << dst);
+        }
+    return MIRT_OK;
+}
+
 // The cull step on the device, for the uploaded scene: no host copy of the flags in either direction.
 extern "C" int mirt_cull_device(const mirt_view *view, int flags)
 {
@@ -1424,11 +1575,7 @@ extern "C" int mirt_cull_device(const mirt_view *view, int flags)
     const int half = next_si();
     hipStream_t st = g.streams[half];
     (void)hipGetLastError();                     // drop a stale error of another HIP user in this thread (see call_begin)
-    for (int r = 0; r < MAX_FLIGHT; r++)         // a frame of another stream may still be copying this copy's previous flags
-        if ((g.cull_read_src[r] >> half & 1u) && r != half) {
-            HIP_TRY(hipStreamWaitEvent(st, g.ev_cull_read[r], 0));
-            g.cull_read_src[r] &= ~(1u << half);
-        }
+    if ((rc = cull_copy_wait_readers(half, st))) return rc;   // a frame of another stream may still be copying this copy's previous flags
     hipLaunchKernelGGL(k_cull, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, g.d_tris, g.n, cp, g.d_culled + (size_t)half * g.n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g.ev_order[half], st));
@@ -1609,6 +1756,7 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
         // and a ray-traced frame took that turn): bring them over, ordered after the cull kernel
         const int from = g.culled_latest;
         HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_order[from], 0));
+        if ((rc = cull_copy_wait_readers(g.si, g.stream))) return rc;   // ... and after any stream still copying OUT of this stream's copy
         HIP_TRY(hipMemcpyAsync(g.d_culled + (size_t)g.si * g.n, g.d_culled + (size_t)from * g.n, (size_t)g.n, hipMemcpyDeviceToDevice, g.stream));
         g.culled_ver[g.si] = g.culled_ver[from];
         HIP_TRY(hipEventRecord(g.ev_cull_read[g.si], g.stream));       // (a later cull step into copy `from` must not overtake this read)
@@ -1644,9 +1792,9 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     f.fd = static_cast<float *>(d_fd);
     f.focal_plane = g.dof_focal;
     if ((rc = raster_scratch_ensure(scratch, g.n, view->width, y1 - y0))) return fail(rc, "raster scratch allocation failed");
-    if (g.profiling) for (int k = MIRT_K_RASTER_SETUP; k <= MIRT_K_CLEAR; k++) g.ev_used[k] = true;
     g.raster_since_sync = true;
-    if ((rc = launch_raster(f, scratch, g.scene_version * 0x9E3779B97F4A7C15ull + g.cull_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr)))
+    if ((rc = launch_raster(f, scratch, g.scene_version * 0x9E3779B97F4A7C15ull + g.cull_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr,
+                            g.profiling ? g.ev_used : nullptr)))
         return fail(rc, "rasteriser launch failed: %s", hipGetErrorString(hipGetLastError()));
     call_end();
     return MIRT_OK;
@@ -1748,6 +1896,11 @@ extern "C" int mirt_get_stats(mirt_stats *out)
 #endif
             g.stats.primary_rays = g.pending_primary;
             g.stats.shadow_rays = (uint64_t)hits * (uint64_t)g.pending_nlights;
+            if (g.stats.mode_used == MIRT_RT_BINNED && g.stats_sel_count) {
+                uint32_t nsel = 0;
+                HIP_TRY(hipMemcpy(&nsel, g.stats_sel_count, 4, hipMemcpyDeviceToHost));
+                g.stats.selected_triangles = nsel;
+            }
             if (g.stats.mode_used == MIRT_RT_BRUTE && !g.pending_counted)      // every ray tests every triangle
                 g.stats.tests = (g.stats.primary_rays + g.stats.shadow_rays) * (uint64_t)g.n;
             if (g.stats.candidates == 0) g.stats.candidates = g.stats.tests;        // kernels that test every candidate they are offered
@@ -1807,10 +1960,114 @@ extern "C" int mirt_band_plan(int world, int root, int width, int height, int nv
 
 extern "C" int mirt_set_partition(int strip_rows)
 {
-    if (strip_rows < 0 || (strip_rows % BIN_TILE) != 0) return fail(MIRT_ERR_INVALID_ARGUMENT, "strip height %d must be 0 (bands) or a multiple of %d rows", strip_rows, BIN_TILE);
+    if (strip_rows != MIRT_PARTITION_WEIGHTED && (strip_rows < 0 || (strip_rows % BIN_TILE) != 0))
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "strip height %d must be 0 (bands), a multiple of %d rows, or MIRT_PARTITION_WEIGHTED", strip_rows, BIN_TILE);
     if (g.init) HIP_TRY(sync_all());
     g.strip_rows = strip_rows;
     return MIRT_OK;
+}
+
+extern "C" int mirt_set_cost_histogram(int on)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    g.want_hist = on != 0;
+    return MIRT_OK;
+}
+
+// pairs-equivalents a tile costs whatever its list holds (part_weighted_bounds); MIRT_PART_TILE_WEIGHT overrides
+static unsigned part_tile_weight()
+{
+    static const unsigned w = [] { const char *e = getenv("MIRT_PART_TILE_WEIGHT"); long v = e ? atol(e) : -1; return v >= 0 ? (unsigned)v : 12u; }();
+    return w;
+}
+
+extern "C" int mirt_weighted_bounds(const uint32_t *hist, int hist_rows, int hist_shift, int width, int height, int world, int32_t *bounds)
+{
+    if (world < 1 || width < 1 || height < 0 || !bounds || hist_rows < 0 || hist_shift < 0 || hist_shift > 16 || (hist_rows > 0 && !hist))
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "weighted bounds: world %d frame %dx%d, %d histogram rows, shift %d", world, width, height, hist_rows, hist_shift);
+    std::vector<int> b((size_t)world + 1);
+    part_weighted_bounds(hist, hist_rows, hist_shift, width, height, world, part_tile_weight(), b.data());
+    for (int r = 0; r <= world; r++) bounds[r] = b[(size_t)r];
+    return MIRT_OK;
+}
+
+// The newest cost histogram of stream 0's ring that was filed under a sharded call <= max_key (0: any) -- waiting for its
+// event if it has not fired yet.  NULL when there is none.
+static const uint32_t *hist_lookup(uint64_t max_key, int *rows, int *shift)
+{
+    RtScratch &S = g.rt[0];
+    int best = -1;
+    for (int i = 0; i < HIST_RING; i++) {
+        // ring order breaks ties between copies of one key (outside sharded calls every copy carries the same one): the one filed last
+        const int slot = (S.hist_next + HIST_RING - 1 - i) % HIST_RING;
+        if (!S.h_hist || S.hist_key[slot] == 0 || (max_key && S.hist_key[slot] > max_key)) continue;
+        if (best < 0 || S.hist_key[slot] > S.hist_key[best]) best = slot;
+    }
+    if (best < 0) return nullptr;
+    if (hipEventSynchronize(S.ev_hist[best]) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *rows = S.hist_rows[best]; *shift = S.hist_shift[best];
+    return S.h_hist + (size_t)best * SEL_HIST_MAX;
+}
+
+extern "C" int mirt_cost_histogram(uint32_t *hist, int max_rows, int *rows, int *shift)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    int nr = 0, sh = 0;
+    const uint32_t *h = hist_lookup(0, &nr, &sh);
+    if (!h) { if (rows) *rows = 0; if (shift) *shift = 0; return 0; }
+    if (rows) *rows = nr;
+    if (shift) *shift = sh;
+    for (int i = 0; i < nr && i < max_rows && hist; i++) hist[i] = h[i];
+    return nr;
+}
+
+// The bands of the sharded call about to be issued (call number g.shard_calls): equal bands, or -- weighted partition -- bands of
+// equal estimated cost from the histogram filed under the call before the previous one (or an earlier one).  Every rank of a group
+// issues the same calls with the same views, files a histogram in the first binned pass of each call and looks TWO calls back,
+// by which time that pass has long run: same histogram on every rank (integer sums over the same triangles), same integer
+// arithmetic, same bands -- no exchange.  A rank that skipped a pass because nothing had changed (rt_enqueue_binned: reuse) holds an
+// older copy of the SAME view's histogram, i.e. the same numbers.
+static void current_bounds(int world, int W, int H, std::vector<int> &bounds)
+{
+    bounds.assign((size_t)world + 1, 0);
+    int nr = 0, sh = 0;
+    const uint32_t *h = (g.strip_rows == MIRT_PARTITION_WEIGHTED && g.shard_calls >= 2) ? hist_lookup(g.shard_calls - 1, &nr, &sh) : nullptr;
+    // (a histogram of another frame size cannot be this frame's)
+    if (h && nr != ((((H + BIN_TILE - 1) / BIN_TILE) - 1) >> sh) + 1) h = nullptr;
+    if (h) part_weighted_bounds(h, nr, sh, W, H, world, part_tile_weight(), bounds.data());
+    else for (int r = 0; r < world; r++) { int a, b; band_of(r, world, H, &a, &b); bounds[(size_t)r] = a; bounds[(size_t)r + 1] = b; }
+}
+
+extern "C" int mirt_partition_bounds(int world, int width, int height, int32_t *bounds)
+{
+    int rc;
+    if ((rc = need_init())) return rc;
+    if (world < 1 || width < 1 || height < 0 || !bounds) return fail(MIRT_ERR_INVALID_ARGUMENT, "partition bounds: world %d frame %dx%d", world, width, height);
+    std::vector<int> b;
+    current_bounds(world, width, height, b);
+    for (int r = 0; r <= world; r++) bounds[r] = b[(size_t)r];
+    return MIRT_OK;
+}
+
+extern "C" int mirt_bounds_plan(int world, int root, int width, int height, int nviews, const int32_t *bounds, uint64_t *root_offset, uint64_t *band_offset,
+                                uint64_t *bytes, int32_t *peer, int max_pieces)
+{
+    if (world < 1 || root < 0 || root >= world || width < 1 || height < 0 || nviews < 1 || max_pieces < 0 || !bounds)
+        return fail(MIRT_ERR_INVALID_ARGUMENT, "bounds plan: world %d root %d frame %dx%d views %d", world, root, width, height, nviews);
+    for (int r = 0; r < world; r++)
+        if (bounds[r] < 0 || bounds[r + 1] < bounds[r] || bounds[r + 1] > height) return fail(MIRT_ERR_INVALID_ARGUMENT, "bounds plan: boundaries must rise from 0 to %d", height);
+    std::vector<int> b(bounds, bounds + world + 1);
+    std::vector<BandPiece> plan((size_t)std::max(max_pieces, 1));
+    const int n = part_gather_plan(world, root, width, height, nviews, 0, plan.data(), max_pieces, b.data());
+    for (int i = 0; i < n && i < max_pieces; i++) {
+        if (root_offset) root_offset[i] = plan[i].root_offset;
+        if (band_offset) band_offset[i] = plan[i].band_offset;
+        if (bytes) bytes[i] = plan[i].bytes;
+        if (peer) peer[i] = plan[i].peer;
+    }
+    return n;
 }
 
 extern "C" int mirt_partition_segments(int rank, int world, int height, int strip_rows, int32_t *y0, int32_t *y1, int max_segments)
@@ -1902,15 +2159,24 @@ static int render_sharded(const mirt_view *views, int nviews, int root, void *d_
     if (world > 1 && rank == root && pitch_bytes != W * 4) return fail(MIRT_ERR_INVALID_ARGUMENT, "a sharded frame needs a dense root buffer (pitch == 4 * width)");
     if (world > 1 && g.in_flight != 1) return fail(MIRT_ERR_INVALID_ARGUMENT, "sharded frames overlap through the band buffers: use mirt_set_frames_in_flight(1)");
     const size_t frame_bytes = (size_t)H * (size_t)pitch_bytes;
+    // (a sharded call is what cost histograms are filed under, one per call: current_bounds)
+    struct CallScope {
+        CallScope() { g.in_sharded = true; g.hist_taken = false; }
+        ~CallScope() { g.in_sharded = false; g.shard_calls++; }
+    } scope;
     if (world == 1) {
         for (int v = 0; v < nviews; v++)
             if ((rc = render(&views[v], 0, H, 0, static_cast<char *>(d_frames) + (size_t)v * frame_bytes, pitch_bytes))) return rc;
         return MIRT_OK;
     }
-    // this rank's rows: one contiguous band, or interleaved strips (mirt_set_partition) -- a band buffer holds the segments of
-    // one view back to back
-    const int segs = part_segments(rank, world, H, g.strip_rows);
-    const size_t band_row = (size_t)W * 4, my_bytes = (size_t)part_rows(rank, world, H, g.strip_rows) * band_row;
+    // this rank's rows: one contiguous band -- an equal share of the rows, or of the estimated cost (weighted partition) --, or
+    // interleaved strips (mirt_set_partition); a band buffer holds the segments of one view back to back
+    std::vector<int> wb;
+    const int *bounds = nullptr;
+    const int strips = g.strip_rows > 0 ? g.strip_rows : 0;
+    if (g.strip_rows == MIRT_PARTITION_WEIGHTED) { current_bounds(world, W, H, wb); bounds = wb.data(); }
+    const int segs = part_segments(rank, world, H, strips, bounds);
+    const size_t band_row = (size_t)W * 4, my_bytes = (size_t)part_rows(rank, world, H, strips, bounds) * band_row;
     const int slot = g.band_slot;
     g.band_slot ^= 1;
     if (rank == root) {
@@ -1918,7 +2184,7 @@ static int render_sharded(const mirt_view *views, int nviews, int root, void *d_
         for (int v = 0; v < nviews; v++)
             for (int k = 0; k < segs; k++) {
                 int y0, y1;
-                part_segment(rank, world, H, g.strip_rows, k, &y0, &y1);
+                part_segment(rank, world, H, strips, k, &y0, &y1, bounds);
                 if (y1 > y0 && (rc = render(&views[v], y0, y1, 0, static_cast<char *>(d_frames) + (size_t)v * frame_bytes, pitch_bytes))) return rc;
             }
     } else {
@@ -1938,7 +2204,7 @@ static int render_sharded(const mirt_view *views, int nviews, int root, void *d_
             int before = 0;                                  // rows of this view's earlier segments in the band buffer
             for (int k = 0; k < segs; k++) {
                 int y0, y1;
-                part_segment(rank, world, H, g.strip_rows, k, &y0, &y1);
+                part_segment(rank, world, H, strips, k, &y0, &y1, bounds);
                 // (row y of the segment lands at row before + (y - y0) of this view's part of the buffer)
                 if (y1 > y0 && (rc = render(&views[v], y0, y1, y0 - before, g.d_band[slot] + (size_t)v * my_bytes, (int)band_row))) return rc;
                 before += y1 - y0;
@@ -1948,9 +2214,9 @@ static int render_sharded(const mirt_view *views, int nviews, int root, void *d_
     // the one exchange step: every band to the root, on the communication stream, overlapping the next call's render
     HIP_TRY(hipEventRecord(g.ev_rendered, g.stream));
     HIP_TRY(hipStreamWaitEvent(g.comm_stream, g.ev_rendered, 0));
-    const int maxp = part_gather_plan(world, root, W, H, nviews, g.strip_rows, nullptr, 0);
+    const int maxp = part_gather_plan(world, root, W, H, nviews, strips, nullptr, 0, bounds);
     std::vector<BandPiece> plan((size_t)std::max(maxp, 1));
-    const int np = part_gather_plan(world, root, W, H, nviews, g.strip_rows, plan.data(), (int)plan.size());
+    const int np = part_gather_plan(world, root, W, H, nviews, strips, plan.data(), (int)plan.size(), bounds);
     std::vector<GatherPiece> pieces;
     for (int i = 0; i < np; i++) {
         if (plan[i].bytes == 0) continue;

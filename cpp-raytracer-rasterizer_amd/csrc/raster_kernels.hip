@@ -480,6 +480,9 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
             const TriSetup &st = f.scratch.setup[lane];
             const int r0 = st.r0, rows = st.rows;
             const size_t base = f.scratch.row_base[lane];
+            // (a triangle whose rows do not fit the span table was not walked: the frame is incomplete, and mirt_sync says so --
+            // the edge kernels raise the same flag, this one does not rely on them)
+            if (rows > 0 && base + (size_t)rows > f.scratch.cap_rows) atomicExch(&f.scratch.counters[1], 1u);
             if (rows > 0 && y >= r0 && y < r0 + rows && base + (size_t)rows <= f.scratch.cap_rows) {
                 const float4 *src = reinterpret_cast<const float4 *>(f.scratch.spans + base + (uint32_t)(y - r0));
                 const float4 a = src[0], b = src[1], c = src[2];      // {ax, dx, azinv, zstep | ap.xyz, pstep.x | pstep.yz, tri, y}
@@ -669,10 +672,12 @@ static uint64_t frame_key(const RasterFrame &f, uint64_t scene_version)
 }
 
 // Enqueues the whole rasteriser frame on `stream`.  ev (nullable) = the library's per-kernel event pairs,
-// indexed 2*MIRT_K_*.  Returns 0 or a negative mirt_status.
-int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev)
+// indexed 2*MIRT_K_*, ev_used (nullable) = which of them this frame recorded.  Returns 0 or a negative mirt_status.
+int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev, bool *ev_used)
 {
-    auto begin = [&](int k) { if (ev) (void)hipEventRecord(ev[2 * k], stream); };
+    // (ev_used[k]: this frame recorded kernel slot k -- a path that skips a kernel, k_raster_small for one, must not report the
+    // times an earlier frame of the stream left in that slot's events)
+    auto begin = [&](int k) { if (ev) { (void)hipEventRecord(ev[2 * k], stream); if (ev_used) ev_used[k] = true; } };
     auto end = [&](int k) { if (ev) (void)hipEventRecord(ev[2 * k + 1], stream); };
     const int band_rows = f.y1 - f.y0;
 

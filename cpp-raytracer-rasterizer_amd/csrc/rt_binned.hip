@@ -186,6 +186,96 @@ __device__ __forceinline__ void bin_walk_large(const BinItem &u, uint32_t utri, 
 #endif
 }
 
+// ---- k_prep_select: the camera's origin rows for the triangles the frame can see, and their list ---------------------------------
+// First kernel of a binned frame (it takes over k_prep_origin's duties there).  One thread per triangle: the origin row -- the
+// very code of k_prep_origin, so the same bits --, then frame_may_see (rt_binned.hpp).  A triangle that may be seen gets its row
+// written and its index appended to `sel` (one global atomic per wave); k_bin_pairs walks that list instead of the scene, and a
+// frame that falls back to brute force (k_rt_trace2) walks it too.  For a band of a sharded frame that is an eighth of the scene,
+// which is what makes the band's binning cost follow the band.
+// The histogram (optional): every boxed triangle adds the bins of its box, row by row, to the coarse tile rows of the WHOLE
+// frame -- whatever rows this call renders -- an estimate of where the frame's (tile, triangle) pairs lie that every rank of a
+// sharded frame computes identically (integer sums), so that all of them derive the same cost-weighted bands without exchanging
+// anything (mirt_capi.hip: weighted partition).  Kept in LDS per workgroup, flushed once.
+constexpr int SEL_WG = 1024;                          // threads of a k_prep_select workgroup: one workgroup per CU, 4 waves per SIMD
+constexpr int SEL_STAGE = 8192;                       // indices a workgroup stages in LDS between hand-overs to the global list (32 KiB)
+
+// (An atomic per wave on the list's length -- the first version -- serialised: one address retires an atomic every ~7 ns, and the
+// 15 600 waves of a 1 M-triangle scene made that 109 us, more than everything the selection saves.  Now a workgroup stages the
+// indices it keeps in LDS and reserves its slice of the list ONCE, when it has walked all its chunks or the stage is full: 256
+// atomics per launch, and the indices leave as coalesced runs.)
+__global__ __launch_bounds__(SEL_WG) void k_prep_select(const float *__restrict__ tris15, int n, const BinFrameDesc fr, const SelectOut out)
+{
+    __shared__ uint32_t s_hist[SEL_HIST_MAX];
+    __shared__ uint32_t s_sel[SEL_STAGE];
+    __shared__ uint32_t s_fill, s_base;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0) {
+        if (out.zero_hits)
+            for (int g = threadIdx.x; g < HIT_SHARDS * HIT_SHARD_STRIDE; g += SEL_WG) out.zero_hits[g] = 0ull;
+        if (out.zero_counter && (threadIdx.x == 0 || (threadIdx.x >= 16 && threadIdx.x < 80))) out.zero_counter[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) *out.sel_count_next = 0u;
+    }
+    if (out.hist && threadIdx.x < SEL_HIST_MAX) s_hist[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_fill = 0u;
+    __syncthreads();
+    const v3 S = V3(fr.S[0], fr.S[1], fr.S[2]);
+    const int nchunks = (n + SEL_WG - 1) / SEL_WG;
+    const int hist_rows = ((fr.nbv - 1) >> out.hist_shift) + 1;
+    // hands the staged indices over to the global list (called by all threads)
+    auto flush = [&]() {
+        __syncthreads();
+        const uint32_t staged = s_fill;
+        if (threadIdx.x == 0 && staged) s_base = atomicAdd(out.sel_count, staged);
+        __syncthreads();
+        const uint32_t base = s_base;
+        for (uint32_t i = threadIdx.x; i < staged; i += SEL_WG) out.sel[base + i] = s_sel[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_fill = 0u;
+        __syncthreads();
+    };
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        if (s_fill + (uint32_t)SEL_WG > (uint32_t)SEL_STAGE) flush();       // (uniform: s_fill only changes between the barriers below)
+        const int i = c * SEL_WG + (int)threadIdx.x;
+        bool keep = false;
+        OriginRow r;
+        if (i < n) {
+            const float *t15 = tris15 + (size_t)15 * i;
+            r = make_origin_row(t15, S);
+            PreBox box;
+            bool boxed;
+            keep = frame_may_see(r, ld3(t15), ld3(t15 + 3), ld3(t15 + 6), fr, &box, &boxed);
+            if (out.hist && boxed) {
+                // the bins of the box, clamped to the grid (floats far outside the int range clamp first)
+                const float flo_u = fmaxf(ceilf(box.lou) - 1.0f, 0.0f), fhi_u = fminf(floorf(box.hiu), (float)(fr.nbu - 1));
+                const float flo_v = fmaxf(ceilf(box.lov) - 1.0f, 0.0f), fhi_v = fminf(floorf(box.hiv), (float)(fr.nbv - 1));
+                if (flo_u <= fhi_u && flo_v <= fhi_v) {
+                    const uint32_t wi = (uint32_t)((int)fhi_u - (int)flo_u + 1);
+                    const int ja = (int)flo_v, jb = (int)fhi_v;
+                    for (int cr = ja >> out.hist_shift; cr <= (jb >> out.hist_shift) && cr < hist_rows; cr++) {
+                        const int lo = max(ja, cr << out.hist_shift), hi = min(jb, ((cr + 1) << out.hist_shift) - 1);
+                        atomicAdd(&s_hist[cr], wi * (uint32_t)(hi - lo + 1));
+                    }
+                }
+            }
+            if (keep) out.cam_tab[i] = r;
+        }
+        // the wave's kept indices into the stage: one LDS atomic per wave
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (m) {
+            uint32_t at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&s_fill, (uint32_t)__popcll(m));
+            at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+            if (keep) s_sel[at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        }
+        __syncthreads();                                  // s_fill as every thread will read it at the top of the next round
+    }
+    flush();
+    if (out.hist && threadIdx.x < SEL_HIST_MAX) {
+        const uint32_t v = s_hist[threadIdx.x];
+        if (v && (int)threadIdx.x < hist_rows) atomicAdd(&out.hist[threadIdx.x], v);
+    }
+}
+
 // What the flattened bin-by-bin tests need of a direct item, in LDS: A2, Bu, Bv and box = {lou, hiu, lov, hiv}, one array per
 // field (neighbouring lanes read neighbouring items: 16-byte stride, where a 64-byte record put them on the same banks).
 
@@ -198,6 +288,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
     __shared__ float4 s_A2[256], s_Bu[256], s_Bv[256], s_box[256];
     __shared__ uint32_t s_org[256];                   // i_lo | j_lo << 16 of a direct item's box
     __shared__ uint32_t s_ni[256];                    // its width in bins
+    __shared__ uint32_t s_tri[256];                   // its triangle
     __shared__ uint32_t s_pre[257];                   // exclusive prefix of the box sizes
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base, s_fill, s_valid;
@@ -206,7 +297,14 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
     // 100 k triangles is only 391 items of 256 for 256 CUs, each a serial ~10 us; with 64 the setup of an item occupies one
     // wave and its flattened tests still use all four
     const int chunk_tris = bs.chunk_tris;
-    const int nchunks = (n + chunk_tris - 1) / chunk_tris, nwork = nchunks * bs.nframes;
+    // Work items: (chunk of the scene, frame) -- except for the frame of the camera's origin table when k_prep_select has listed
+    // the triangles it can see (bs.sel): that frame's items are the chunks of the list, and they come first.
+    const int nchunks = (n + chunk_tris - 1) / chunk_tris;
+    const bool listed = bs.sel != nullptr;            // (then frame 0 is the camera's: rt_enqueue_binned)
+    const uint32_t nsel = listed ? min(*bs.sel_count, (uint32_t)n) : 0u;
+    const int ncam = listed ? (int)((nsel + (uint32_t)chunk_tris - 1u) / (uint32_t)chunk_tris) : 0;
+    const int nrest = listed ? bs.nframes - 1 : bs.nframes;
+    const int nwork = ncam + nchunks * nrest;
     if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
     if (bs.bucket_cnt)
         for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += BIN_WG) s_bucket[b] = 0u;
@@ -245,8 +343,13 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
 #ifdef MIRT_BIN_STAMPS
         st_t = __builtin_amdgcn_s_memtime();
 #endif
-        const int chunk = w / bs.nframes, frame = w - chunk * bs.nframes;
-        const uint32_t tri0 = (uint32_t)chunk * (uint32_t)chunk_tris, tri = tri0 + threadIdx.x;
+        int chunk, frame;
+        if (w < ncam) { chunk = w; frame = 0; }
+        else { const int w2 = w - ncam; chunk = w2 / nrest; frame = w2 - chunk * nrest + (listed ? 1 : 0); }
+        const uint32_t slot = (uint32_t)chunk * (uint32_t)chunk_tris + threadIdx.x;      // place in the list (camera frame) or in the scene
+        const bool from_list = w < ncam;
+        const uint32_t nhere = from_list ? nsel : (uint32_t)n;
+        const uint32_t tri = ((int)threadIdx.x < chunk_tris && slot < nhere) ? (from_list ? bs.sel[slot] : slot) : 0xFFFFFFFFu;
         const BinFrameDesc fr = bs.frames ? bs.frames[frame] : bs.frame0;
         BinFrameGrid gr;
         gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base; gr.nshell = (uint32_t)max(fr.nshell, 1);
@@ -262,7 +365,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
         int i_lo = 0, i_hi = -1, j_lo = 0, j_hi = -1;
         unsigned long long cells = 0;                     // huge items: level-0 cells (first 64) that may hold a hit
         uint32_t shell = 0;                               // depth shell of the triangle in this frame (orders the bins' lists)
-        if ((int)threadIdx.x < chunk_tris && tri < (uint32_t)n && fj1 > fj0) {
+        if (tri < (uint32_t)n && fj1 > fj0) {
             const OriginRow &row = (fr.tab == 0) ? cam_tab[tri] : light_tab[(size_t)(fr.tab - 1) * n + tri];
             shell = bin_shell_of(fr, row.r1.w);
             TriBinFns t = make_bin_fns(row, fr);
@@ -353,6 +456,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
             s_box[threadIdx.x] = make_float4(it.lou, it.hiu, it.lov, it.hiv);
             s_org[threadIdx.x] = (uint32_t)i_lo | ((uint32_t)j_lo << 16);
             s_ni[threadIdx.x] = ni | (shell << 8);
+            s_tri[threadIdx.x] = tri;
         }
         __syncthreads();
         const uint32_t t0w = s_wave[0], t1w = s_wave[1], t2w = s_wave[2], t3w = s_wave[3];
@@ -400,7 +504,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
                               (__builtin_fmaf(FJ, Bv.w, __builtin_fmaf(FI, Bu.w, A2.w)) >= 0.0f) &&
                               (FI + 1.0f >= box.x) && (FI <= box.y) && (FJ + 1.0f >= box.z) && (FJ <= box.w);   // = cell_may_hit(.., A2, i, j, 1)
                     key[q] = (gr.fbase + (uint32_t)j * (uint32_t)nbu + (uint32_t)i) * gr.nshell + sh;
-                    val[q] = tri0 + lo;
+                    val[q] = s_tri[lo];
                 }
             }
             // one LDS atomic per wave and round hands out the slots of all its passing tests

@@ -87,6 +87,23 @@ struct BinSet {
     uint32_t nbuckets;
     int bucket_shift;
     int chunk_tris;               // triangles per work item of k_bin_pairs: 256 or 64
+    // the camera frame's triangles, when k_prep_select has chosen them (nullable: every triangle): the work items of the frame
+    // whose origin table is the camera's (tab == 0) walk this list instead of the scene
+    const uint32_t *sel;
+    const uint32_t *sel_count;
+};
+
+// What k_prep_select leaves behind for the frame's other kernels, per stream.
+constexpr int SEL_HIST_MAX = 256;      // coarse tile rows of the cost histogram (a frame's tile rows >> hist_shift)
+struct SelectOut {
+    OriginRow *cam_tab;           // rows of the SELECTED triangles only (the others keep whatever an earlier frame left)
+    uint32_t *sel;                // their indices (n slots)
+    uint32_t *sel_count;          // how many; zero on entry
+    uint32_t *sel_count_next;     // the counter the NEXT pass will use: zeroed here
+    uint32_t *hist;               // nullable: SEL_HIST_MAX words, += estimated (tile, triangle) pairs per coarse tile row of the WHOLE frame
+    int hist_shift;
+    unsigned long long *zero_hits;   // nullable: the frame's hit counters (k_prep_origin's duty as first kernel of a frame)
+    uint32_t *zero_counter;          // nullable: the binning pass's counters: [0] and [16..79] are zeroed
 };
 
 // The unsorted (bin, triangle) pair list k_bin_pairs writes and bin_sort.hip orders by bin.
@@ -213,6 +230,89 @@ __device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const B
     // the pushed-out triangle contains the original one; keep that explicit against rounding of the offsets
     t.bu0 = fminf(bu0, u0 - slack); t.bu1 = fmaxf(bu1, u1 + slack); t.bv0 = fminf(bv0, v0 - slack); t.bv1 = fmaxf(bv1, v1 + slack);
     t.bstate = BOX_VALID;
+}
+
+// ---- the cheap pre-test in front of all that (k_prep_select) -------------------------------------------------------------------
+// A frame that renders a BAND of rows (one rank of a sharded frame: mirt_raytrace_sharded) binned every triangle of the scene
+// for it: origin row, edge functions and box of add_bbox() -- about a thousand instructions -- for the seven eighths of the
+// triangles that cannot reach the band.  This test costs a sixth of that and settles most of them.  It is add_bbox()'s own
+// argument with a coarser box: for a triangle whose three vertices lie clearly in front of the family's projection plane, every
+// accepted ray lies inside the projected triangle with its edge lines pushed out by d = the largest margin distance of the three
+// edge functions; vertex i of that pushed-out triangle sits d / sin(angle_i / 2) from the projected vertex, and
+//     sin(angle_i / 2) >= sin(angle_i) / 2 = area2 / (2 * l_a * l_b) >= area2 / (2 * (extu^2 + extv^2))
+// bounds every such offset by  disp = 2 * dd * (extu^2 + extv^2) / area2  (dd = 1.25 * d as in add_bbox) without a square root
+// or a division per corner.  The box [u0 - disp, u1 + disp] x [v0 - disp, v1 + disp] therefore CONTAINS add_bbox()'s; a frame
+// whose rows and columns it misses (by a whole bin more than add_bbox()'s own conversion would ask for) holds no pair of the
+// triangle.  Reciprocals and reciprocal square roots are the hardware's one-ulp approximations; the projection's pad carries
+// 2^-21 per quotient instead of add_bbox()'s 2^-22 for them, margin distances and the displacement are raised by 2^-19.
+// Everything else -- a vertex near or behind the plane, a vanishing area, an origin in the triangle's plane (|e1e2b| below the
+// threshold k_bin_pairs uses for "either sign"), any NaN -- answers "may be seen" and leaves the decision to the full set-up.
+// Returns false only when NO ray of rows [j0, j1) x columns [0, nbu) of the frame can be accepted on the triangle; *boxed says
+// whether the box outputs (bin-index ranges over the whole grid, unclamped floats) are valid -- the cost histogram uses them.
+struct PreBox { float lou, hiu, lov, hiv; };
+__device__ __forceinline__ bool frame_may_see(const OriginRow &row, v3 va, v3 vb, v3 vc, const BinFrameDesc &fr, PreBox *box, bool *boxed)
+{
+    *boxed = false;
+    const float nbv = row.r0.w;
+    if (!(fabsf(nbv) >= 1.6940658945086007e-21f)) return true;            // either sign of e1e2d may pass t >= 0 (k_bin_pairs: `both`); also NaN
+    const v3 vert[3] = { va, vb, vc };
+    float us[3], vs[3], pad = 0.0f;
+    int front = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float gx = fr.S[0] - vert[j].x, gy = fr.S[1] - vert[j].y, gz = fr.S[2] - vert[j].z;
+        const float w = fr.rw[0] * gx + fr.rw[1] * gy + fr.rw[2] * gz;
+        const float wm = fabsf(fr.rw[0] * gx) + fabsf(fr.rw[1] * gy) + fabsf(fr.rw[2] * gz);
+        front += (w > 0.00390625f * wm);
+        const float un = fr.ru[0] * gx + fr.ru[1] * gy + fr.ru[2] * gz, vn = fr.rv[0] * gx + fr.rv[1] * gy + fr.rv[2] * gz;
+        const float um = fabsf(fr.ru[0] * gx) + fabsf(fr.ru[1] * gy) + fabsf(fr.ru[2] * gz);
+        const float vm = fabsf(fr.rv[0] * gx) + fabsf(fr.rv[1] * gy) + fabsf(fr.rv[2] * gz);
+        const float iw = __builtin_amdgcn_rcpf(w);
+        us[j] = un * iw; vs[j] = vn * iw;
+        const float aiw = fabsf(iw);
+        pad = fmaxf(pad, 4.76837158203125e-07f * ((um + fabsf(us[j]) * wm) * aiw + (vm + fabsf(vs[j]) * wm) * aiw) +
+                             4.76837158203125e-07f * (fabsf(us[j]) + fabsf(vs[j])));
+    }
+    if (front != 3) return true;
+    // margin distances of the three edge functions p, q, s = n - p - q (make_edge_fn / make_bin_fns: same gradients, same margins)
+    float cu[3], cv[3], mg[3];
+    const float4 rr[3] = { row.r0, row.r1, row.r2 };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        cu[k] = rr[k].x * fr.Pu[0] + rr[k].y * fr.Pu[1] + rr[k].z * fr.Pu[2];
+        cv[k] = rr[k].x * fr.Pv[0] + rr[k].y * fr.Pv[1] + rr[k].z * fr.Pv[2];
+        mg[k] = 7.62939453125e-06f * ((fabsf(rr[k].x) + fabsf(rr[k].y) + fabsf(rr[k].z)) * fr.dmax) + 9.5367431640625e-07f;
+    }
+    const float scu = cu[0] - cu[1] - cu[2], scv = cv[0] - cv[1] - cv[2], sm = 1.25f * (mg[0] + mg[1] + mg[2]);
+    const float dp = mg[1] * __builtin_amdgcn_rsqf(cu[1] * cu[1] + cv[1] * cv[1]);
+    const float dq = mg[2] * __builtin_amdgcn_rsqf(cu[2] * cu[2] + cv[2] * cv[2]);
+    const float ds = sm * __builtin_amdgcn_rsqf(scu * scu + scv * scv);
+    const float d = fmaxf(fmaxf(dp, dq), ds) * 1.0000019073486328125f + pad;
+    const float u0 = fminf(fminf(us[0], us[1]), us[2]), u1 = fmaxf(fmaxf(us[0], us[1]), us[2]);
+    const float v0 = fminf(fminf(vs[0], vs[1]), vs[2]), v1 = fmaxf(fmaxf(vs[0], vs[1]), vs[2]);
+    const float extu = u1 - u0, extv = v1 - v0;
+    const float ax = us[1] - us[0], ay = vs[1] - vs[0], bx = us[2] - us[0], by = vs[2] - vs[0];
+    const float t1 = ax * by, t2 = ay * bx;
+    // the area from below: every vertex may be off by `pad` (the area changes by at most pad * perimeter, doubled; the perimeter of
+    // a triangle is at most that of its box) and the cross product cancels (2^-21 of its two products)
+    const float area_lo = fabsf(t1 - t2) - 4.0f * pad * (extu + extv) - 4.76837158203125e-07f * (fabsf(t1) + fabsf(t2));
+    if (!(area_lo > 0.0f)) return true;                                    // (also NaN)
+    const float disp = (2.5f * d) * (extu * extu + extv * extv) * __builtin_amdgcn_rcpf(area_lo) * 1.0000019073486328125f;
+    const float slack = 2.0f * pad + 1.0e-6f * fmaxf(extu, extv);
+    const float bu0 = u0 - disp - slack, bu1 = u1 + disp + slack, bv0 = v0 - disp - slack, bv1 = v1 + disp + slack;
+    if (!(bu0 > -1.0e30f && bu1 < 1.0e30f && bv0 > -1.0e30f && bv1 < 1.0e30f)) return true;   // also NaN
+    // bin-index ranges as k_bin_pairs converts add_bbox()'s box (bin i passes `i + 1 >= lou && i <= hiu`), widened likewise
+    const float idu = __builtin_amdgcn_rcpf(fr.du), idv = __builtin_amdgcn_rcpf(fr.dv);
+    PreBox b;
+    b.lou = (bu0 - fr.ulo - fr.pad_hi) * idu; b.hiu = (bu1 - fr.ulo - fr.pad_lo) * idu;
+    b.lov = (bv0 - fr.vlo - fr.pad_hi) * idv; b.hiv = (bv1 - fr.vlo - fr.pad_lo) * idv;
+    b.lou -= 7.62939453125e-06f * (1.0f + fabsf(b.lou)); b.hiu += 7.62939453125e-06f * (1.0f + fabsf(b.hiu));
+    b.lov -= 7.62939453125e-06f * (1.0f + fabsf(b.lov)); b.hiv += 7.62939453125e-06f * (1.0f + fabsf(b.hiv));
+    *box = b;
+    *boxed = true;
+    // a whole bin of room on every side beyond what the conversion asks for
+    const bool miss = (b.hiu < -1.0f) || (b.lou > (float)fr.nbu + 1.0f) || (b.hiv < (float)fr.j0 - 1.0f) || (b.lov > (float)fr.j1 + 1.0f);
+    return !miss;
 }
 
 __device__ __forceinline__ void fn_range(const EdgeFn &e, float u0, float u1, float v0, float v1, float *lo, float *hi)

@@ -251,6 +251,8 @@ struct RtTraceFrame {
                                       // segments of order_seg records
     const uint32_t *order_count;      // records in each segment
     uint32_t order_seg;               // room per segment = the most pairs a group can have = waves per group
+    const uint32_t *sel;              // the triangles k_prep_select found the frame may see, and how many: what a frame that fell
+    const uint32_t *sel_count;        // back to brute force walks (their origin rows are the ones the frame has built)
 };
 
 // One wave renders one PAIR of horizontally adjacent tiles.  Two things decide which wave takes which pair:
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
     const int rs = AA ? f.aa : 1;                          // realSamples (:549-554); compile-time 1 without supersampling
 
     const uint32_t begA = rec.beg, begB = rec.beg + rec.nA;
-    const uint32_t nA = brute ? (uint32_t)f.n : rec.nA, nB = brute ? (enB ? (uint32_t)f.n : 0u) : rec.nB;
+    const uint32_t nall = brute ? min((uint32_t)__builtin_amdgcn_readfirstlane((int)*tf.sel_count), (uint32_t)f.n) : 0u;
+    const uint32_t nA = brute ? nall : rec.nA, nB = brute ? (enB ? nall : 0u) : rec.nB;
     const uint32_t nmax = max(nA, nB);
     const float4 *geo4 = reinterpret_cast<const float4 *>(tf.geo);
     TM_SEG(0)
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                 const int sh = lane >> 4, sj = lane & 15;  // lanes 0..15 stage tile A's candidates, 16..31 tile B's
                 const bool stage = lane < 32 && sj < (sh ? cntB : cntA);
                 if (stage) {
-                    const uint32_t idx = brute ? base + (uint32_t)sj : tf.cam_entries[(sh ? begB : begA) + base + (uint32_t)sj];
+                    const uint32_t idx = brute ? tf.sel[base + (uint32_t)sj] : tf.cam_entries[(sh ? begB : begA) + base + (uint32_t)sj];
                     const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
                     const float4 a0 = src[0], a1 = src[1], a2 = src[2];
                     const float4 *gsrc = geo4 + (size_t)idx * 3;

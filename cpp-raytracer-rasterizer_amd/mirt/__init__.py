@@ -22,7 +22,8 @@ EXPORTS = (
     "mirt_stream", "mirt_scene_upload", "mirt_scene_set_culled", "mirt_scene_size", "mirt_scene_cornell",
     "mirt_scene_soup", "mirt_scene_load_stl", "mirt_cull", "mirt_cull_device", "mirt_scene_get_culled", "mirt_set_soft_shadows", "mirt_set_antialiasing", "mirt_set_depth_of_field", "mirt_set_frames_in_flight", "mirt_raytrace", "mirt_raytrace_device", "mirt_raytrace_ex", "mirt_raytrace_device_ex", "mirt_rasterise",
     "mirt_rasterise_device", "mirt_get_stats", "mirt_get_previous_kernel_ms", "mirt_surface_register", "mirt_surface_unregister", "mirt_raytrace_async", "mirt_rasterise_async",
-    "mirt_band_of", "mirt_band_plan", "mirt_set_partition", "mirt_partition_segments", "mirt_partition_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_comm_selfcheck", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
+    "mirt_band_of", "mirt_band_plan", "mirt_set_partition", "mirt_partition_segments", "mirt_partition_plan",
+    "mirt_set_cost_histogram", "mirt_cost_histogram", "mirt_weighted_bounds", "mirt_partition_bounds", "mirt_bounds_plan", "mirt_comm_create_id", "mirt_comm_init", "mirt_comm_shutdown", "mirt_comm_selfcheck", "mirt_raytrace_sharded", "mirt_rasterise_sharded",
 )
 
 
@@ -42,7 +43,8 @@ class Light(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("tests", C.c_uint64),
                 ("gpu_ms", C.c_float), ("kernel_ms", C.c_float * 8), ("mode_used", C.c_int32), ("candidates", C.c_uint64),
-                ("steps_primary", C.c_uint64), ("steps_shadow", C.c_uint64), ("drains", C.c_uint64)]
+                ("steps_primary", C.c_uint64), ("steps_shadow", C.c_uint64), ("drains", C.c_uint64),
+                ("bins_reused", C.c_uint32), ("selected_triangles", C.c_uint32)]
 
 
 _vp = C.c_void_p
@@ -92,6 +94,11 @@ def load():
     lib.mirt_set_partition.argtypes = [C.c_int]
     lib.mirt_partition_segments.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int]
     lib.mirt_partition_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]
+    lib.mirt_set_cost_histogram.argtypes = [C.c_int]
+    lib.mirt_cost_histogram.argtypes = [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mirt_weighted_bounds.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+    lib.mirt_partition_bounds.argtypes = [C.c_int, C.c_int, C.c_int, _vp]
+    lib.mirt_bounds_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
     lib.mirt_comm_create_id.argtypes = [_vp]
     lib.mirt_comm_init.argtypes = [_vp, C.c_int, C.c_int]
     lib.mirt_comm_selfcheck.argtypes = [C.c_size_t]
@@ -182,7 +189,8 @@ def stats():
     _check(load().mirt_get_stats(C.byref(s)))
     return {"primary_rays": s.primary_rays, "shadow_rays": s.shadow_rays, "tests": s.tests, "gpu_ms": s.gpu_ms,
             "kernel_ms": dict(zip(KERNEL_NAMES, list(s.kernel_ms))), "mode_used": s.mode_used, "candidates": s.candidates,
-            "steps_primary": s.steps_primary, "steps_shadow": s.steps_shadow, "drains": s.drains}
+            "steps_primary": s.steps_primary, "steps_shadow": s.steps_shadow, "drains": s.drains,
+            "bins_reused": int(s.bins_reused), "selected_triangles": int(s.selected_triangles)}
 
 
 # ---- scene ------------------------------------------------------------------------------------------
@@ -427,6 +435,51 @@ def partition_plan(world, root, width, height, nviews, strip_rows):
         _check(n)
     ro, bo, by, pe = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.int32)
     load().mirt_partition_plan(world, root, width, height, nviews, strip_rows, _ptr(ro), _ptr(bo), _ptr(by), _ptr(pe), n)
+    return [(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(ro[:n], bo[:n], by[:n], pe[:n])]
+
+
+PARTITION_WEIGHTED = -1
+
+
+def set_cost_histogram(on):
+    """Binned ray-traced frames leave the cost histogram of the whole frame (mirt_set_cost_histogram)."""
+    _check(load().mirt_set_cost_histogram(1 if on else 0))
+
+
+def cost_histogram():
+    """(hist, shift) of the latest binned frame -- estimated (tile, triangle) pairs per coarse tile row of (1 << shift) tile rows --
+    or (None, 0)."""
+    h = np.zeros(256, np.uint32)
+    rows, shift = C.c_int(), C.c_int()
+    n = load().mirt_cost_histogram(_ptr(h), 256, C.byref(rows), C.byref(shift))
+    if n < 0:
+        _check(n)
+    return (h[:n].copy(), shift.value) if n > 0 else (None, 0)
+
+
+def weighted_bounds(hist, shift, width, height, world):
+    """world + 1 row boundaries of bands of equal estimated cost (mirt_weighted_bounds; pure arithmetic, no device)."""
+    h = np.ascontiguousarray(hist if hist is not None else np.zeros(0), np.uint32)
+    b = np.zeros(world + 1, np.int32)
+    _check(load().mirt_weighted_bounds(_ptr(h) if len(h) else None, len(h), int(shift), int(width), int(height), int(world), _ptr(b)))
+    return [int(x) for x in b]
+
+
+def partition_bounds(world, width, height):
+    """The boundaries the next sharded call will use (mirt_partition_bounds)."""
+    b = np.zeros(world + 1, np.int32)
+    _check(load().mirt_partition_bounds(int(world), int(width), int(height), _ptr(b)))
+    return [int(x) for x in b]
+
+
+def bounds_plan(world, root, width, height, nviews, bounds):
+    """[(root_offset, band_offset, bytes, peer)] of one gather for explicit band boundaries (mirt_bounds_plan)."""
+    bd = np.ascontiguousarray(bounds, np.int32)
+    n = load().mirt_bounds_plan(world, root, width, height, nviews, _ptr(bd), None, None, None, None, 0)
+    if n < 0:
+        _check(n)
+    ro, bo, by, pe = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.int32)
+    load().mirt_bounds_plan(world, root, width, height, nviews, _ptr(bd), _ptr(ro), _ptr(bo), _ptr(by), _ptr(pe), n)
     return [(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(ro[:n], bo[:n], by[:n], pe[:n])]
 
 

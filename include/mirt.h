@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define MIRT_API __attribute__((visibility("default")))
-#define MIRT_ABI_VERSION 3
+#define MIRT_ABI_VERSION 4
 #define MIRT_MAX_LIGHTS 32            /* Light lights[32], raytracer.cpp:48 / rasteriser.cpp:50 */
 
 typedef enum mirt_status {
@@ -85,6 +85,11 @@ typedef struct mirt_stats {
     uint64_t steps_primary;
     uint64_t steps_shadow;
     uint64_t drains;
+    /* binned ray tracer (ABI 4): 1 when the frame started at the trace kernel -- nothing its binning pass depends on had changed
+     * since the stream's last pass (the view stood still: a light key, a toggle; raytracer.cpp:385-537) --, and how many of the
+     * scene's triangles the rows of the call can see at all (what its binning pass walked; 0 when no pass ran) */
+    uint32_t bins_reused;
+    uint32_t selected_triangles;
 } mirt_stats;
 
 /* indices into mirt_stats.kernel_ms */
@@ -286,8 +291,26 @@ MIRT_API int mirt_band_plan(int world, int root, int width, int height, int nvie
  *                     at the granularity a GPU launch needs (64).  Each strip is a launch chain of its own.
  * mirt_partition_segments / mirt_partition_plan: a rank's row segments [y0[k], y1[k]) and the gather's messages for either
  * partition (mirt_band_of / mirt_band_plan are the strip_rows == 0 case); a band buffer holds a rank's segments of one view back
- * to back.  Pure arithmetic, no device needed; both return the count (arrays nullable, at most max_* entries written). */
+ * to back.  Pure arithmetic, no device needed; both return the count (arrays nullable, at most max_* entries written).
+ *   MIRT_PARTITION_WEIGHTED   contiguous bands of equal ESTIMATED COST instead of equal height: the counterpart of
+ *                     `schedule(auto)` for a frame whose rows differ in what they cost (a triangle soup seen in perspective: the
+ *                     middle bands of BASELINE configs[4] hold twice the candidates of the outer ones).  The first kernel of
+ *                     a binned ray-traced frame leaves an estimate of the (tile, triangle) pairs per tile row of the WHOLE frame;
+ *                     every rank computes the same numbers from the same scene and view, and the bands of sharded call c come
+ *                     from the histogram of call c - 2 by integer arithmetic -- identical on every rank, nothing exchanged.
+ *                     Equal bands until a histogram exists (the first two calls, frames that take another path).
+ * mirt_weighted_bounds: that arithmetic as a pure function (world + 1 boundaries, multiples of 8 rows, from a histogram of
+ * hist_rows coarse tile rows of (1 << hist_shift) tile rows each); mirt_partition_bounds: the boundaries the NEXT sharded call
+ * will use; mirt_bounds_plan: the gather's messages for explicit boundaries; mirt_set_cost_histogram(1) makes binned frames
+ * leave the histogram outside sharded calls too and mirt_cost_histogram returns the latest one (returns its row count, 0: none). */
+#define MIRT_PARTITION_WEIGHTED (-1)
 MIRT_API int mirt_set_partition(int strip_rows);
+MIRT_API int mirt_set_cost_histogram(int on);
+MIRT_API int mirt_cost_histogram(uint32_t *hist, int max_rows, int *rows, int *shift);
+MIRT_API int mirt_weighted_bounds(const uint32_t *hist, int hist_rows, int hist_shift, int width, int height, int world, int32_t *bounds);
+MIRT_API int mirt_partition_bounds(int world, int width, int height, int32_t *bounds);
+MIRT_API int mirt_bounds_plan(int world, int root, int width, int height, int nviews, const int32_t *bounds, uint64_t *root_offset,
+                              uint64_t *band_offset, uint64_t *bytes, int32_t *peer, int max_pieces);
 MIRT_API int mirt_partition_segments(int rank, int world, int height, int strip_rows, int32_t *y0, int32_t *y1, int max_segments);
 MIRT_API int mirt_partition_plan(int world, int root, int width, int height, int nviews, int strip_rows, uint64_t *root_offset,
                                  uint64_t *band_offset, uint64_t *bytes, int32_t *peer, int max_pieces);

@@ -19,7 +19,7 @@ def test_header_symbols_all_exported():
     lib = mirt.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mirt_abi_version() == 3
+    assert lib.mirt_abi_version() == 4
 
 
 def test_struct_layouts_match_reference_sizes():

@@ -82,6 +82,98 @@ def test_strip_partition_and_its_gather_plan(world, root, W, H, nviews, strip):
     assert [s for r in range(world) for s in mirt.partition_segments(r, world, H, 0)] == [b for b in (mirt.band_of(r, world, H) for r in range(world)) if b[1] > b[0]]
 
 
+def _weighted_bounds_reference(hist, shift, W, H, world, tile_weight=12):
+    """csrc/comm.cpp: part_weighted_bounds, restated with Python integers (exact)."""
+    tile_rows, tiles_x = (H + 7) // 8, (W + 7) // 8
+    cost = []
+    for j in range(tile_rows):
+        c = j >> shift
+        first, last = c << shift, min(tile_rows, (c + 1) << shift)
+        h = int(hist[c]) if hist is not None and c < len(hist) else 0
+        cost.append(h // max(last - first, 1) + tile_weight * tiles_x + 1)
+    prefix = [0]
+    for c in cost:
+        prefix.append(prefix[-1] + c)
+    total, bounds, j = prefix[-1], [0], 0
+    for r in range(1, world):
+        want = total * r
+        while j < tile_rows and prefix[j + 1] * world <= want:
+            j += 1
+        cut = j
+        if j < tile_rows and prefix[j + 1] * world - want < want - prefix[j] * world:
+            cut = j + 1
+        prev = (bounds[r - 1] + 7) // 8
+        if tile_rows >= world:
+            cut = min(max(cut, prev + 1), tile_rows - (world - r))
+        cut = max(cut, prev)
+        bounds.append(min(cut * 8, H))
+    bounds.append(H)
+    for r in range(1, world + 1):
+        bounds[r] = max(bounds[r], bounds[r - 1])
+    return bounds, cost
+
+
+@pytest.mark.parametrize("H,W", [(4320, 7680), (1080, 1920), (131, 200), (64, 64), (9, 40), (0, 8)])
+def test_weighted_bounds_split_the_estimated_cost_evenly(H, W):
+    """mirt_weighted_bounds (MIRT_PARTITION_WEIGHTED): boundaries rise from 0 to H on tile rows, every rank keeps a tile row while
+    there are enough, no band's cost is farther from the even share than one tile row's cost, and the result is the integer
+    arithmetic of the restatement above -- what makes every rank of a group derive the same bands."""
+    tile_rows = (H + 7) // 8
+    shift = 0
+    while ((max(tile_rows, 1) - 1) >> shift) + 1 > 256:
+        shift += 1
+    rows = ((max(tile_rows, 1) - 1) >> shift) + 1
+    rng = np.random.RandomState(H + W)
+    y = (np.arange(rows) + 0.5) / rows
+    hists = {"none": None, "flat": np.full(rows, 100000, np.uint32), "zero": np.zeros(rows, np.uint32),
+             "middle": (4e6 * np.exp(-((y - 0.5) / 0.2) ** 2)).astype(np.uint32), "top": (3e6 * (1 - y) ** 3).astype(np.uint32),
+             "noise": rng.randint(0, 1 << 22, rows).astype(np.uint32), "one_row": (np.arange(rows) == rows // 3).astype(np.uint32) * np.uint32(4000000000)}
+    for name, hist in hists.items():
+        for world in (1, 2, 3, 4, 8, 9):
+            got = mirt.weighted_bounds(hist, shift, W, H, world)
+            want, cost = _weighted_bounds_reference(hist, shift, W, H, world)
+            assert got == want, (name, world, got, want)
+            assert got[0] == 0 and got[-1] == H and all(a <= b for a, b in zip(got, got[1:]))
+            assert all(b % 8 == 0 or b == H for b in got)
+            if tile_rows >= world:
+                assert all(b > a for a, b in zip(got, got[1:])), (name, world, got)
+            if H and name != "one_row":
+                share = sum(cost) / world
+                for a, b in zip(got, got[1:]):
+                    band = sum(cost[a // 8:(b + 7) // 8])
+                    assert abs(band - share) <= 2 * max(cost) + 1, (name, world, got, band, share)
+    # equal costs give (nearly) equal bands; a peak in the middle makes the middle bands the shortest
+    flat = mirt.weighted_bounds(hists["flat"], shift, W, H, 4)
+    if tile_rows >= 8:
+        sizes = [b - a for a, b in zip(flat, flat[1:])]
+        assert max(sizes) - min(sizes) <= 16
+        mid = mirt.weighted_bounds(hists["middle"], shift, W, H, 4)
+        msizes = [b - a for a, b in zip(mid, mid[1:])]
+        assert msizes[1] <= msizes[0] and msizes[2] <= msizes[3]
+
+
+@pytest.mark.parametrize("world,root,W,H,nviews", [(2, 0, 16, 40, 1), (3, 1, 7, 100, 2), (8, 0, 6, 432, 2), (5, 4, 3, 9, 1), (4, 2, 5, 64, 3)])
+def test_explicit_bounds_and_their_gather_plan(world, root, W, H, nviews):
+    """Bands with explicit boundaries (what the weighted partition hands to the gather): the plan's byte moves rebuild every frame."""
+    rng = np.random.RandomState(world * 77 + H)
+    cuts = sorted(int(c) for c in rng.choice(np.arange(0, H + 1), world - 1))
+    bounds = [0] + cuts + [H]
+    full = rng.randint(0, 2 ** 32, (nviews, H, W), dtype=np.uint64).astype(np.uint32)
+    bands = {r: np.ascontiguousarray(full[:, bounds[r]:bounds[r + 1], :]).view(np.uint8).reshape(-1) for r in range(world)}
+    frames = np.zeros((nviews, H, W), np.uint32)
+    frames[:, bounds[root]:bounds[root + 1]] = full[:, bounds[root]:bounds[root + 1]]
+    flat = frames.view(np.uint8).reshape(-1)
+    plan = mirt.bounds_plan(world, root, W, H, nviews, bounds)
+    assert all(p[3] != root for p in plan)
+    for ro, bo, nbytes, peer in plan:
+        flat[ro:ro + nbytes] = bands[peer][bo:bo + nbytes]
+    assert np.array_equal(frames, full)
+    equal = [mirt.band_of(r, world, H)[0] for r in range(world)] + [H]
+    assert mirt.bounds_plan(world, root, W, H, nviews, equal) == mirt.band_plan(world, root, W, H, nviews)
+    with pytest.raises(mirt.MirtError):
+        mirt.bounds_plan(world, root, W, H, nviews, [0] + [H + 8] * world)
+
+
 def test_cpp_world_size_2_partition_and_assembly(tmp_path):
     """tests/cpp/band_plan_test.cpp: one process per rank, bands through pipes in plan order, every word checked."""
     exe = str(tmp_path / "band_plan_test")
@@ -124,8 +216,15 @@ for kind, scene in (("rt", "cornell"), ("rt", "soup"), ("raster", "cornell"), ("
     mirt.scene_upload(tris, mirt.cull(tris, views[0], 0) if kind == "raster" else None)
     frames = DeviceArray((3, H, W), np.uint32, 0x33) if rank == root else None
     mode = mirt.RT_BINNED if scene == "soup" else mirt.RT_AUTO
-    for rep in range(3):                     # several gathers in a row: both band buffers, events
+    reps = 5 if strip < 0 else 3             # several gathers in a row: both band buffers, events; the weighted partition (strip -1)
+    for rep in range(reps):                  # takes its bands from the histogram of the call before the previous one
+        segs_root = [tuple(mirt.partition_bounds(world, W, H)[root:root + 2])] if strip < 0 else mirt.partition_segments(root, world, H, strip)
         mirt.prepared_sharded(kind, views, L, (0.2, 0.2, 0.2), mode, root, frames.ptr if frames else None, W * 4)()
+    if strip < 0 and scene == "soup" and world > 1:
+        # the soup is binned, so by now the bands come from a histogram: not the equal split any more (3 000 triangles around the
+        # box crowd the middle rows)
+        used = mirt.partition_bounds(world, W, H)
+        assert used != [mirt.band_of(r, world, H)[0] for r in range(world)] + [H], used
     mirt.sync()
     if rank == root:
         got = frames.read()
@@ -141,7 +240,7 @@ for kind, scene in (("rt", "cornell"), ("rt", "soup"), ("raster", "cornell"), ("
                 border = np.zeros((H, W), bool)
                 border[0, :] = border[-1, :] = True; border[:, 0] = border[:, -1] = True
                 own = np.zeros((H, W), bool)
-                for ry0, ry1 in mirt.partition_segments(root, world, H, strip):
+                for ry0, ry1 in segs_root:
                     own[ry0:ry1] = True
                 want[border & own] = 0x33333333
                 want[border & ~own] = 0
@@ -157,7 +256,7 @@ sys.exit(0 if ok else 1)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,root,strip", [(2, 0, 0), (3, 1, 0), (2, 1, 16), (3, 0, 8)])
+@pytest.mark.parametrize("world,root,strip", [(2, 0, 0), (3, 1, 0), (2, 1, 16), (3, 0, 8), (2, 0, -1), (3, 1, -1)])
 def test_sharded_frames_through_the_loopback_transport(tmp_path, world, root, strip):
     code = RANK_CODE % {"pkg": os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), "tests": os.path.join(ROOT, "tests")}
     env = dict(os.environ, MIRT_COMM="shm", MIRT_TEST_STRIP_ROWS=str(strip))

@@ -191,3 +191,75 @@ def test_cull_on_the_device_is_ordered_between_frames_in_flight(oracle, device):
         mirt.set_frames_in_flight(1)
         for b in surf + idx:
             b.free()
+
+
+# ---- the cull flags' way through the streams: the sequences the call-sequence fuzzer caught in round 3, as deterministic tests ----
+# ops: ("cull", view) = mirt_cull_device for that view; ("rt",) = a ray-traced frame (takes a stream's turn, reads no flags);
+# ("raster", view) / ("band", view, part) = a rasterised frame / its upper (0) or lower (1) half.  Every rasterised frame must show
+# the flags of the most recent cull step, whatever stream it lands on.
+_CULL_SEQUENCES = {
+    # cull -> ray-trace -> rasterise: the ray-traced frame takes the stream the cull step wrote the flags for
+    "cull_raytrace_rasterise": [op for k in range(8) for op in (("cull", k % 2), ("rt",), ("raster", k % 2))],
+    # frames drawn WITHOUT a cull step reuse the latest flags across streams
+    "frames_without_a_cull_step": [("cull", 0), ("raster", 0), ("raster", 1), ("raster", 0), ("rt",), ("raster", 1), ("cull", 1), ("raster", 1),
+                                   ("raster", 0), ("rt",), ("rt",), ("raster", 0), ("raster", 1), ("cull", 0), ("rt",), ("raster", 1), ("raster", 0)],
+    # a stream reads two different copies in turn, then a cull step goes into the first of them
+    "two_copies_then_a_cull_into_the_first": [("cull", 0), ("rt",), ("raster", 0), ("cull", 1), ("rt",), ("rt",), ("raster", 1), ("cull", 0), ("raster", 0),
+                                              ("rt",), ("raster", 1), ("cull", 1), ("rt",), ("raster", 0), ("raster", 1)] * 2,
+    # two bands per frame, a cull step per frame: with three frames in flight the second band's hand-over copy overwrites a copy
+    # another stream may still be reading (advisor finding of round 3: raster_enqueue did not wait for such readers)
+    "two_bands_per_frame": [op for k in range(9) for op in (("cull", k % 2), ("band", k % 2, 0), ("band", k % 2, 1))],
+    # ... and a cull step every other frame only
+    "two_bands_cull_every_other_frame": [op for k in range(10) for op in ((("cull", (k // 2) % 2),) if k % 2 == 0 else ()) + (("band", k % 2, 0), ("band", k % 2, 1))],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_flight", [2, 3, 4])
+@pytest.mark.parametrize("name", sorted(_CULL_SEQUENCES))
+def test_cull_flags_follow_the_frames_through_the_streams(oracle, device, name, in_flight):
+    """Cross-stream hand-over of the cull flags (mirt_cull_device / raster_enqueue) on a mesh large enough (120 k triangles) for the
+    kernels of consecutive calls to overlap; every rasterised frame against the oracle's frame for (its view, the flags of the most
+    recent cull step)."""
+    from devbuf import DeviceArray
+    tris = mirt.scene_soup(9, 120000, 0.03)
+    W, H = 320, 180
+    cams = [((0.0, 0.0, -3.0), 0.0), ((0.9, 0.1, -2.4), 0.5)]
+    rots = [oracle.rot_from_yaw(yaw, 1.01) for _, yaw in cams]
+    vs = [mirt.make_view(cam, rots[i], float(H), W, H) for i, (cam, _) in enumerate(cams)]
+    culled = [oracle.cull(tris, cams[j][0], rots[j], float(H), W, H, 3) for j in range(2)]
+    assert not np.array_equal(culled[0], culled[1])
+    cache = {}
+
+    def want(i, j):                                         # view i drawn with the flags view j's cull step left
+        if (i, j) not in cache:
+            cache[(i, j)] = oracle.rasterise(tris, culled[j], cams[i][0], rots[i], float(H), W, H, DEFAULT_LIGHT, want=("xrgb",))["xrgb"]
+        return cache[(i, j)]
+
+    mirt.scene_upload(tris)
+    mirt.set_frames_in_flight(in_flight)
+    scratch = DeviceArray((H, W), np.uint32, 0x5A)
+    outs, checks = [], []
+    try:
+        flags = None
+        for op in _CULL_SEQUENCES[name]:
+            if op[0] == "cull":
+                mirt.cull_device(vs[op[1]], 3)
+                flags = op[1]
+            elif op[0] == "rt":
+                mirt.raytrace_device(vs[0], DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, 0, H, 0, scratch.ptr, W * 4)
+            else:
+                y0, y1 = (0, H) if op[0] == "raster" else ((0, H // 2) if op[2] == 0 else (H // 2, H))
+                buf = DeviceArray((H, W), np.uint32, 0x5A)
+                outs.append(buf)
+                mirt.rasterise_device(vs[op[1]], DEFAULT_LIGHT, (0.2, 0.2, 0.2), y0, y1, 0, buf.ptr, W * 4)
+                checks.append((buf, op[1], flags, y0, y1))
+        mirt.sync()
+        for n, (buf, i, j, y0, y1) in enumerate(checks):
+            got = buf.read()
+            assert np.array_equal(got[y0:y1], want(i, j)[y0:y1]), "rasterised call %d (view %d, flags of view %d, rows %d..%d): %d words differ" % (
+                n, i, j, y0, y1, int((got[y0:y1] != want(i, j)[y0:y1]).sum()))
+    finally:
+        mirt.set_frames_in_flight(1)
+        for b in outs + [scratch]:
+            b.free()

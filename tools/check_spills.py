@@ -18,16 +18,25 @@ with tempfile.TemporaryDirectory() as tmp:
         if not name.endswith(".hip"):
             continue
         out = os.path.join(tmp, name + ".s")
-        subprocess.check_call(["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, name), "-o", out], stderr=subprocess.DEVNULL)
+        cc = subprocess.run(["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, name), "-o", out], capture_output=True, text=True)
+        if cc.returncode != 0:
+            sys.stderr.write(cc.stderr)
+            sys.exit("tools/check_spills.py: hipcc failed on %s (rc %d)" % (name, cc.returncode))
         text = open(out).read()
         # the per-kernel resource comments the backend emits: "; Kernel ... " blocks end with NumVgprs / ScratchSize / Occupancy
         for m in re.finditer(r"^\s*\.set (\S+)\.uses_flat_scratch.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text, re.S | re.M):
-            kern = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().split("(")[0]
+            kern = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
             rows.append((name, kern, int(m.group(2)), int(m.group(3)), int(m.group(4))))
             if int(m.group(3)):
                 bad.append(rows[-1])
 for r in rows:
     print("%-22s %-44s vgprs %3d scratch %4d occupancy %d" % r)
+# the gate must not pass vacuously: should the backend's resource comments change shape, the pattern above matches nothing
+EXPECT = ("k_rt_trace2", "k_rt_tile2", "k_rt_brute", "k_bin_pairs", "k_raster_small", "k_raster_resolve", "k_dof_tile", "k_bs_local")
+missing = [k for k in EXPECT if not any(k in r[1] for r in rows)]
+if missing or len(rows) < 20:
+    sys.exit("tools/check_spills.py: resource summaries found for %d kernels only; missing %s -- the pattern no longer matches the backend's output"
+             % (len(rows), missing))
 if bad:
     print("SPILLS:", [(b[1], b[3]) for b in bad])
     sys.exit(1)

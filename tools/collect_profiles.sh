@@ -11,13 +11,18 @@ shift || true
 if [ "$stage" = pmc ]; then
   # (optionally: tools/collect_profiles.sh pmc <workload> ... -- a gpurun call is at most 20 minutes)
   [ $# -gt 0 ] || set -- soup100k cornell1080 raster4k soup1m8k raster4kdof8 cornell1080dof8
+  # the digest of the device code the counters are about to count: taken HERE, on the box that runs them, and only copied later
+  stamp=$(python3 -c "import bench; print(bench.csrc_digest())")
+  export MIRT_BENCH_TARGET_S=0.1            # (a profiled run is about launches, not about a long timed region)
   for t in "$@"; do
     steps=20; [ $t = soup1m8k ] && steps=4
     tools/prof.sh $t --workload $t --steps $steps --warmup 3 > /dev/null 2>&1; echo "trace $t rc=$?"
     tools/pmc_hbm.sh $t --workload $t --steps $((steps / 2)) --warmup 2 > /dev/null 2>&1
     python tools/pmc_summary.py gpurun_out/pmc_$t > gpurun_out/pmc_$t/summary.json
+    echo $stamp > gpurun_out/pmc_$t/csrc_sha16.txt
     tools/pmc_valu.sh $t --workload $t --steps $((steps / 2)) --warmup 2 > gpurun_out/pmcv_$t.txt 2>&1
     python tools/pmc_issue_summary.py gpurun_out/pmcv_$t > gpurun_out/pmcv_$t/summary.json; echo "pmc $t rc=$?"
+    echo $stamp > gpurun_out/pmcv_$t/csrc_sha16.txt
     # the per-dispatch tables are tens of MiB per pass (gpurun merges at most 64 MiB back): the summaries are what is kept
     find gpurun_out/prof_$t gpurun_out/pmc_$t gpurun_out/pmcv_$t -name "*counter_collection.csv" -delete -o -name "*kernel_trace.csv" -delete
   done
