@@ -518,6 +518,10 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
         finish_batch()
         env.fence()
         kernel_ms_alone = {k: v / an for k, v in aacc.items() if v > 0}
+    # the binned kernel keeps its own counts (tests executed, candidates offered) only for frames rendered with profiling on --
+    # five scalar instructions per filter step that the frames of the timed loop do without: the last profiled frame has them
+    mirt.sync()
+    st_prof = mirt.stats()
     mirt.set_profiling(False)
 
     static = None
@@ -594,7 +598,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                      mirt.RT_BINNED: "k_rt_trace2"}[st["mode_used"]]
             # algorithmic flops per launch = ray-triangle tests the launch executed x 60 flop per test as written in the
             # reference (brute force: rays x triangles; tile / binned kernels: filter evaluations counted in-kernel)
-            tests_rank = float(st["tests"])
+            tests_rank = float(st_prof["tests"])
             ach = tests_rank * FLOP_PER_TEST / (kt * 1e-3) / 1e12 if kt > 0 else None
             out["roofline"] = {"bound": "valu", "kernel": kname, "achieved": None if ach is None else round(ach, 3),
                                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None if ach is None else round(ach / PEAK_FP32_TFLOPS, 4),
@@ -604,7 +608,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                                    "understate what the vector pipes do; issue slots do not)",
                                "traffic": measured_traffic(name, [kname]) if world == 1 else None,
                                "traffic_source": "profiles/%s_hbm_traffic.json (rocprofv3 PMC, bytes per launch)" % ROUND,
-                               "tests_per_launch": int(tests_rank), "candidates_per_launch": int(st["candidates"]), "kernel_ms": round(kt, 5),
+                               "tests_per_launch": int(tests_rank), "candidates_per_launch": int(st_prof["candidates"]), "kernel_ms": round(kt, 5),
                                "kernel_ms_mode": "hipEvents around the launch on its own stream, %d frame(s) in flight, %s camera%s" % (in_flight, "moving" if moving else "static", "; the frame before the last of 6 queued back to back (overlapped on both sides)" if overlapped else ""),
                                "reference_tests_per_launch": int(rays_rank * len(tris)),
                                "reference_equivalent_tflops": None if kt <= 0 else round(rays_rank * len(tris) * FLOP_PER_TEST / (kt * 1e-3) / 1e12, 3),
@@ -629,7 +633,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 out["roofline"]["valu_issue"] = {"instructions_per_launch": int(insts), "achieved": round(ipc, 4), "peak": ISSUE_CEILING,
                                                  "unit": "wave-instr/clk/SIMD", "frac": round(ipc / ISSUE_CEILING, 4),
                                                  "lane_slots_per_test": round(insts * 64.0 / max(tests_rank, 1.0), 1),
-                                                 "lane_slots_per_candidate": round(insts * 64.0 / max(float(st["candidates"]), 1.0), 1),
+                                                 "lane_slots_per_candidate": round(insts * 64.0 / max(float(st_prof["candidates"]), 1.0), 1),
                                                  "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}
                 # every instruction kind over the launch ALONE on the device: the stream as a whole against the issue rate
                 if kernel_ms_alone and kernel_ms_alone.get("trace", 0.0) > 0:

@@ -87,9 +87,17 @@ __global__ __launch_bounds__(256) void k_bs_scatter(const uint32_t *__restrict__
         for (int j = 0; j < BS_PER_THREAD; j++)
             if (k[j] != 0xFFFFFFFFu) rank[j] = atomicAdd(&s_cnt[k[j] >> shift], 1u);
         __syncthreads();
-        for (uint32_t b = threadIdx.x; b < nbuckets; b += 256) {
-            const uint32_t c = s_cnt[b];
-            if (c) s_cnt[b] = s_base[b] + atomicAdd(&cursor[b], c);      // where this workgroup's pairs of bucket b go
+        // where this workgroup's pairs of each bucket go: one returning global atomic per (workgroup, bucket) -- four buckets per
+        // thread at a time, their atomics in flight TOGETHER (one after the other, each waiting for its answer, they were most of
+        // the ~14 us an iteration took on the 1 M-triangle frame: every workgroup hits every bucket's counter)
+        for (uint32_t b0 = threadIdx.x; b0 < nbuckets; b0 += 1024) {
+            uint32_t c[4], at[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint32_t b = b0 + 256u * q; c[q] = b < nbuckets ? s_cnt[b] : 0u; at[q] = 0u; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (c[q]) at[q] = atomicAdd(&cursor[b0 + 256u * q], c[q]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (c[q]) s_cnt[b0 + 256u * q] = s_base[b0 + 256u * q] + at[q];
         }
         __syncthreads();
 #pragma unroll

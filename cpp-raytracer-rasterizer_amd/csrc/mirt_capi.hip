@@ -60,7 +60,7 @@ struct RtTraceFrame {                            // (rt_trace.hip)
     const uint32_t *sel;
     const uint32_t *sel_count;
 };
-template <bool AA> __global__ void k_rt_trace2(const RtTraceFrame);
+template <bool AA, bool STATS> __global__ void k_rt_trace2(const RtTraceFrame);
 __global__ void k_prep_select(const float *, int, const BinFrameDesc, const SelectOut);
 __global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *, uint32_t);
 __global__ void k_geo_table(const float *, int, GeoRow *, ShadeRow *);
@@ -990,8 +990,15 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     const dim3 tgrid(ORDER_GROUPS * order_seg);             // (workgroup id % 8 = XCD group, id / 8 = the wave among the group's)
     const size_t lds = rt_trace_lds_bytes(1);
     k_begin(MIRT_K_TRACE);
-    if (f.aa > 1) hipLaunchKernelGGL(k_rt_trace2<true>, tgrid, dim3(64), lds, g.stream, tf);
-    else hipLaunchKernelGGL(k_rt_trace2<false>, tgrid, dim3(64), lds, g.stream, tf);
+    // (the kernel's own statistics -- tests, candidates, steps, drains -- only for frames rendered with profiling on: rt_trace.hip)
+    g.pending_counted = g.profiling;
+    if (f.aa > 1) {
+        if (g.profiling) hipLaunchKernelGGL((k_rt_trace2<true, true>), tgrid, dim3(64), lds, g.stream, tf);
+        else hipLaunchKernelGGL((k_rt_trace2<true, false>), tgrid, dim3(64), lds, g.stream, tf);
+    } else {
+        if (g.profiling) hipLaunchKernelGGL((k_rt_trace2<false, true>), tgrid, dim3(64), lds, g.stream, tf);
+        else hipLaunchKernelGGL((k_rt_trace2<false, false>), tgrid, dim3(64), lds, g.stream, tf);
+    }
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
     call_end();

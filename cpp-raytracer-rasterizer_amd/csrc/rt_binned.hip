@@ -302,7 +302,10 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
     const int nchunks = (n + chunk_tris - 1) / chunk_tris;
     const bool listed = bs.sel != nullptr;            // (then frame 0 is the camera's: rt_enqueue_binned)
     const uint32_t nsel = listed ? min(*bs.sel_count, (uint32_t)n) : 0u;
-    const int ncam = listed ? (int)((nsel + (uint32_t)chunk_tris - 1u) / (uint32_t)chunk_tris) : 0;
+    // a SHORT list (the 17 000 triangles the top band of the 1 M-triangle frame at 8K sees: 67 items of 256 for 256 CUs, each a
+    // serial ~10 us of set-up) goes in items of 64: the set-up of an item then occupies one wave, its flattened tests still all eight
+    const int cam_chunk = (listed && nsel < 32768u) ? 64 : chunk_tris;
+    const int ncam = listed ? (int)((nsel + (uint32_t)cam_chunk - 1u) / (uint32_t)cam_chunk) : 0;
     const int nrest = listed ? bs.nframes - 1 : bs.nframes;
     const int nwork = ncam + nchunks * nrest;
     if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
@@ -346,10 +349,11 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
         int chunk, frame;
         if (w < ncam) { chunk = w; frame = 0; }
         else { const int w2 = w - ncam; chunk = w2 / nrest; frame = w2 - chunk * nrest + (listed ? 1 : 0); }
-        const uint32_t slot = (uint32_t)chunk * (uint32_t)chunk_tris + threadIdx.x;      // place in the list (camera frame) or in the scene
         const bool from_list = w < ncam;
+        const int item_tris = from_list ? cam_chunk : chunk_tris;
+        const uint32_t slot = (uint32_t)chunk * (uint32_t)item_tris + threadIdx.x;       // place in the list (camera frame) or in the scene
         const uint32_t nhere = from_list ? nsel : (uint32_t)n;
-        const uint32_t tri = ((int)threadIdx.x < chunk_tris && slot < nhere) ? (from_list ? bs.sel[slot] : slot) : 0xFFFFFFFFu;
+        const uint32_t tri = ((int)threadIdx.x < item_tris && slot < nhere) ? (from_list ? bs.sel[slot] : slot) : 0xFFFFFFFFu;
         const BinFrameDesc fr = bs.frames ? bs.frames[frame] : bs.frame0;
         BinFrameGrid gr;
         gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base; gr.nshell = (uint32_t)max(fr.nshell, 1);

@@ -313,7 +313,12 @@ __global__ __launch_bounds__(64) void k_tile_order(const uint32_t *__restrict__ 
 #ifndef MIRT_TR_WAVES_MIN
 #define MIRT_TR_WAVES_MIN 3
 #endif
-template <bool AA>
+// STATS: the kernel's own counts (tests executed, candidates offered, wave steps of the two filter loops, drains: what
+// mirt_get_stats reports and the roofline's `achieved` is made of).  Keeping them costs five scalar instructions in every step of
+// both filter loops -- a fifth of the scalar stream --, so the frames of a render loop run without them; a frame rendered with
+// profiling on (mirt_set_profiling: the frames whose kernel times bench.py reads) counts.  The hit count -- the frame's shadow rays
+// -- is one atomic per wave and always kept.
+template <bool AA, bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAVES_MIN, MIRT_TR_WAVES))) void k_rt_trace2(const RtTraceFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
@@ -390,8 +395,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
             // drains most of a list is skipped.  The records are only updated by drains, i.e. the bounds lag -- never the result.
             s.best[lane] = MIN_T_NONE; s.best[lane + 64] = MIN_T_NONE;
             s.flag[lane] = 0; s.flag[lane + 64] = 0;
-            ncand += nokA * nA + nokB * nB;
-            float lbA = FLT_MAX, lbB = FLT_MAX;            // distance of the sub-ray's record so far
+            if (STATS) ncand += nokA * nA + nokB * nB;
+            // distance of the sub-ray's record so far; -inf for a lane without a pixel (outside the frame or the rows of this call):
+            // every candidate's `near` lies beyond it, so such a lane never passes the near test below and needs no mask of its own
+            float lbA = okA ? FLT_MAX : -__builtin_huge_valf(), lbB = okB ? FLT_MAX : -__builtin_huge_valf();
             float tbA = FLT_MAX, tbB = FLT_MAX;            // their maxima over the tile's pixels (wave-uniform)
             for (uint32_t base = 0; base < nmax; base += TR_STAGE) {
                 const int cntA = (int)min((uint32_t)TR_STAGE, nA > base ? nA - base : 0u);
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                 while (pm) {
                     const int j = __builtin_ctz(pm);
                     pm &= pm - 1u;
-                    nsteps_p++;
+                    if (STATS) nsteps_p++;
                     const float4 *R = s.rows + 6 * j;
                     const float4 R0 = R[0], R1 = R[1], R2 = R[2], R3 = R[3], R4 = R[4], R5 = R[5];
                     // e1e2d, be2d, e1bd (raytracer.cpp:232-234) of (pixel A, candidate j of list A) and (pixel B, candidate j of list B)
@@ -439,24 +446,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     const unsigned long long filtA = wballot(fm.x >= MAYBE_HIT_THRESHOLD), filtB = wballot(fm.y >= MAYBE_HIT_THRESHOLD);
                     // (a candidate the wave has pruned -- near beyond the record of EVERY pixel of its tile -- fails the per-pixel
                     // test in every lane, and an unfilled slot carries near = +inf: no need to consult pmA / pmB here)
-                    const unsigned long long liveA = okmA & nearA, liveB = okmB & nearB;
-                    const unsigned long long mA = liveA & filtA, mB = liveB & filtB;
+                    // (... nor the masks of the lanes that have a pixel: the others carry a record of -inf)
+                    const unsigned long long mA = nearA & filtA, mB = nearB & filtB;
                     const bool passA0 = (mA >> lane) & 1ull, passB = (mB >> lane) & 1ull;
-                    ntests += (unsigned)__popcll(liveA) + (unsigned)__popcll(liveB);
+                    if (STATS) ntests += (unsigned)__popcll(nearA) + (unsigned)__popcll(nearB);
                     if (mA | mB) {
                         int cA = __popcll(mA);
                         const int cB = __popcll(mB);
                         bool passA = passA0;
                         if (qn + cA + cB > TR_QUEUE) {                             // (rare: no room for this step)
                             TM_SEG(2)
-                            if (qn) { tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; ndrains++; }
+                            if (qn) { tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; if (STATS) ndrains++; }
                             if (cA + cB > TR_QUEUE) {                              // the step alone does not fit: tile A's pairs go first
                                 if (passA) {
                                     const int at = wave_rank(mA);
                                     s.q[at] = make_float4(td.den.x, td.pu.x, td.qv.x, R1.z);
                                     s.qa[at] = make_uint2((uint32_t)lane | ((uint32_t)j << 8), __float_as_uint(R5.z));
                                 }
-                                tr_drain<false>(s, lane, cA, geo4, cam); ndrains++;
+                                tr_drain<false>(s, lane, cA, geo4, cam); if (STATS) ndrains++;
                                 passA = false; cA = 0;
                             }
                             TM_SEG(3)
@@ -474,10 +481,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                         qn += cA + cB;
                         if (qn >= TR_DRAIN) {
                             TM_SEG(2)
-                            do { tr_drain_full<false>(s, lane, qn, geo4, cam); ndrains++; } while (qn >= TR_DRAIN);
+                            do { tr_drain_full<false>(s, lane, qn, geo4, cam); if (STATS) ndrains++; } while (qn >= TR_DRAIN);
                             TM_SEG(3)
-                            lbA = min_t_dist(s.best[lane]); lbB = min_t_dist(s.best[lane + 64]);
-                            tbA = wave_max_f(okA ? lbA : -FLT_MAX); tbB = wave_max_f(okB ? lbB : -FLT_MAX);
+                            lbA = okA ? min_t_dist(s.best[lane]) : lbA; lbB = okB ? min_t_dist(s.best[lane + 64]) : lbB;
+                            tbA = wave_max_f(lbA); tbB = wave_max_f(lbB);
                             pmA &= (uint32_t)wballot(stage && sh == 0 && !(my_near > tbA));
                             pmB &= (uint32_t)(wballot(stage && sh == 1 && !(my_near > tbB)) >> 16);
                             pm &= pmA | pmB;
@@ -488,10 +495,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                 // the records they leave prune the next chunk
                 TM_SEG(2)
                 if (qn) {
-                    tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; ndrains++;
+                    tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; if (STATS) ndrains++;
                     if (base + TR_STAGE < nmax) {
-                        lbA = min_t_dist(s.best[lane]); lbB = min_t_dist(s.best[lane + 64]);
-                        tbA = wave_max_f(okA ? lbA : -FLT_MAX); tbB = wave_max_f(okB ? lbB : -FLT_MAX);
+                        lbA = okA ? min_t_dist(s.best[lane]) : lbA; lbB = okB ? min_t_dist(s.best[lane + 64]) : lbB;
+                        tbA = wave_max_f(lbA); tbB = wave_max_f(lbB);
                     }
                 }
                 TM_SEG(3)
@@ -562,33 +569,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                             eB = tf.light_off[key]; endB = tf.light_off[key + shB + 1u];
                         }
                     }
-                    ncand_l += (endA - eA) + (endB - eB);
-                    // the lane walks list A, then list B.  Per step: the filter; a candidate it lets through is either a CERTAIN
+                    if (STATS) ncand_l += (endA - eA) + (endB - eB);
+                    // The lane walks list A, then list B.  Per step: the filter; a candidate it lets through is either a CERTAIN
                     // occluder (sure_hit, and the whole triangle closer to the light than 0.99 r: nothing left to compute, the ray
-                    // is done) or goes to the exact stage's queue.  The next row is requested once the step knows which it is.
+                    // is done) or goes to the exact stage's queue.
+                    // The walk's state lives in plain integer and float registers and every step is straight-line code: what a lane
+                    // is doing follows from comparisons made afresh each step (active: e < end; list B still to come: on list A and
+                    // eB < endB), the filter and the certain-occluder test are evaluated for every lane, and the next row is loaded by
+                    // every lane (row 0 where a lane has none to fetch).  Written with booleans carried around the loop and the
+                    // tests nested in ifs, the compiler kept each boolean as a scalar lane mask and merged it with exec at every
+                    // divergent join: ~60 scalar instructions per step beside ~30 vector ones -- and at the four waves per SIMD this
+                    // kernel runs at, a scalar instruction costs what a vector one costs (profiles/r03_issue_model.txt).
                     const uint32_t *row_tri = brute ? nullptr : tf.light_tri;
                     const bool firstA = eA < endA;
                     uint32_t e = firstA ? eA : eB, end = firstA ? endA : endB, pix = firstA ? (uint32_t)lane : (uint32_t)lane + 64u;
                     v3 crd = firstA ? half0(rd) : half1(rd);
                     float cthr = firstA ? thr.x : thr.y;
-                    bool pend = firstA && eB < endB;
-                    bool act = e < end;
-                    bool occA = false, occB = false;                 // certain occlusions found by the lane itself
-                    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0, c2 = c0;
-                    if (act) { const float4 *src = rows4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
+                    uint32_t occ = 0u;                               // bit 0 / 1: the lane itself found a certain occluder of pixel A / B
+                    float4 c0, c1, c2;
+                    { const float4 *src = rows4 + (size_t)(e < end ? e : 0u) * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
                     TM_SEG(6)
-                    while (wballot(act)) {
-                        nsteps_s++;
+                    const int not_brute = brute ? 0 : 1;
+                    for (;;) {
+                        const bool act = e < end;
+                        const unsigned long long am = wballot(act);
+                        if (!am) break;
+                        if (STATS) { nsteps_s++; ntests += (unsigned)__popcll(am); }
                         const TestDots td = test_dots(c0, c1, c2, crd);          // negD = rDir (:310, :229)
                         // a candidate none of whose points is closer to the light than 0.99 r cannot occlude (:313)
-                        const bool pass = act && !(c1.w > cthr) && maybe_hit(td);
-                        const bool sure = pass && !brute && c2.w < cthr && sure_hit(td, c0.w);
-                        const bool queue = pass && !sure;
-                        ntests += (unsigned)__popcll(wballot(act));
-                        const unsigned long long m = wballot(queue);
-                        bool occ = sure;
+                        const int pass = (int)act & (int)!(c1.w > cthr) & (int)maybe_hit(td);
+                        const int sure = pass & not_brute & (int)(c2.w < cthr) & (int)sure_hit(td, c0.w);
+                        const int queue = pass & (sure ^ 1);
+                        const unsigned long long m = wballot(queue != 0);
+                        int done = sure;                                          // this list is settled for the lane
                         if (m) {
-                            if (qn + __popcll(m) > TR_QUEUE) { tr_drain<true>(s, lane, qn, geo4, L, row_tri); qn = 0; ndrains++; }   // (rare: no room for this step)
+                            if (qn + __popcll(m) > TR_QUEUE) { tr_drain<true>(s, lane, qn, geo4, L, row_tri); qn = 0; if (STATS) ndrains++; }   // (rare: no room for this step)
                             if (queue) {
                                 const int at = qn + wave_rank(m);
                                 s.q[at] = make_float4(td.den, td.pu, td.qv, c0.w);
@@ -597,23 +612,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                             qn += __popcll(m);
                             if (qn >= TR_DRAIN) {
                                 TM_SEG(7)
-                                do { tr_drain_full<true>(s, lane, qn, geo4, L, row_tri); ndrains++; } while (qn >= TR_DRAIN);
+                                do { tr_drain_full<true>(s, lane, qn, geo4, L, row_tri); if (STATS) ndrains++; } while (qn >= TR_DRAIN);
                                 TM_SEG(8)
-                                occ = occ || (act && s.flag[pix] != 0);         // found occluded: the rest of this list is moot
+                                done |= (int)act & (int)(s.flag[pix] != 0);     // found occluded: the rest of this list is moot
                             }
                         }
-                        if (sure) { if (pix < 64u) occA = true; else occB = true; }
+                        occ |= sure ? (pix < 64u ? 1u : 2u) : 0u;
                         // on: the next row of this list, or -- list done or ray occluded -- the first of list B
-                        const bool cont = act && !occ && e + 1 < end;
-                        const bool sw = act && !cont && pend;
-                        if (sw) { crd = half1(rd); cthr = thr.y; pix = (uint32_t)lane + 64u; end = endB; pend = false; }
-                        e = cont ? e + 1 : eB;
-                        act = cont || sw;
-                        if (act) { const float4 *src = rows4 + (size_t)e * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
+                        const int cont = (int)act & (done ^ 1) & (int)(e + 1u < end);
+                        const int sw = (int)act & (cont ^ 1) & (int)(pix < 64u) & (int)(eB < endB);
+                        crd = sw ? half1(rd) : crd;
+                        cthr = sw ? thr.y : cthr;
+                        pix = sw ? (uint32_t)lane + 64u : pix;
+                        e = cont ? e + 1u : (sw ? eB : end);                     // (neither: e == end, the lane is done)
+                        end = sw ? endB : end;
+                        const float4 *src = rows4 + (size_t)((cont | sw) ? e : 0u) * 3;
+                        c0 = src[0]; c1 = src[1]; c2 = src[2];
                     }
                     TM_SEG(7)
-                    if (qn) { tr_drain<true>(s, lane, qn, geo4, L, row_tri); qn = 0; ndrains++; }
+                    if (qn) { tr_drain<true>(s, lane, qn, geo4, L, row_tri); qn = 0; if (STATS) ndrains++; }
                     TM_SEG(8)
+                    const bool occA = (occ & 1u) != 0u, occB = (occ & 2u) != 0u;
                     // occluded (:313-314); any-hit is exact
                     if (occA || s.flag[lane] != 0) { D.x.x = 0.0f; D.y.x = 0.0f; D.z.x = 0.0f; }
                     if (occB || s.flag[lane + 64] != 0) { D.x.y = 0.0f; D.y.y = 0.0f; D.z.y = 0.0f; }
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
     {
         // tests executed, candidates offered (list entries x rays), wave steps of the two filter loops, drains: one atomic
         // instruction, lane i adding to word 1 + i of the wave's shard
-        ncand += wave_sum(ncand_l);
+        if (STATS) ncand += wave_sum(ncand_l);
         const unsigned shard = (blockIdx.x + (threadIdx.x >> 6) * 61u) % HIT_SHARDS;
 #ifdef MIRT_TR_TIMING
         // (experiments) words 3..12 carry the segments' sums instead of the step counts, word 13 the longest lifetime
@@ -650,7 +669,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
         if (lane < 2 && v) atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 1 + lane, (unsigned long long)v);
 #else
         const unsigned v = lane == 0 ? ntests : lane == 1 ? ncand : lane == 2 ? nsteps_p : lane == 3 ? nsteps_s : ndrains;
-        if (lane < 5 && v) atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 1 + lane, (unsigned long long)v);
+        if (STATS && lane < 5 && v) atomicAdd(f.hit_count + (size_t)shard * HIT_SHARD_STRIDE + 1 + lane, (unsigned long long)v);
 #endif
     }
     if (AA) {                                                      // avgColor /= realSamples^2 (:599); /1 is the identity
@@ -679,8 +698,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
     }
 }
 
-template __global__ void k_rt_trace2<false>(const RtTraceFrame);
-template __global__ void k_rt_trace2<true>(const RtTraceFrame);
+template __global__ void k_rt_trace2<false, false>(const RtTraceFrame);
+template __global__ void k_rt_trace2<false, true>(const RtTraceFrame);
+template __global__ void k_rt_trace2<true, false>(const RtTraceFrame);
+template __global__ void k_rt_trace2<true, true>(const RtTraceFrame);
 
 size_t rt_trace_lds_bytes(int waves) { return (size_t)waves * sizeof(TrWaveLds); }
 

@@ -531,7 +531,11 @@ def test_rt_binned_light_cube_follows_a_moving_light():
         return b["stats"]["tests"]
 
     fixed = np.array([[0.1, -0.4, -0.6, 1, 1, 1, 14]], np.float32)
-    tests = [both(fixed) for _ in range(7)]
+    mirt.set_profiling(True)                              # (the binned kernel keeps its own counts only for profiled frames)
+    try:
+        tests = [both(fixed) for _ in range(7)]
+    finally:
+        mirt.set_profiling(False)
     assert max(tests[4:]) < min(tests[:4]), tests         # (the count varies a little from run to run: early exits race)
     for i in range(4):
         moving = fixed.copy(); moving[0, 0] += 0.05 * (i + 1)
@@ -572,6 +576,69 @@ def test_rt_binned_moving_lights_with_two_frames_in_flight():
             assert np.array_equal(outs[i].read(), want[i]), i
     finally:
         mirt.set_frames_in_flight(1)
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_rt_binned_pass_is_kept_while_the_view_stands_still(in_flight):
+    """The reference redraws with the camera where it was whenever a light key, a toggle or a light added / deleted sets isUpdated
+    (raytracer.cpp:385-537).  A binned frame whose view, rows and scene are those of its stream's last pass starts at the trace
+    kernel (mirt_stats.bins_reused); anything else -- a moved camera, another band, a light binned by the frame that moved, another
+    kind of frame on the stream in between -- runs the pass.  A sequence that alternates moved / unmoved views and lights, whole
+    frames and bands, with a brute-force frame thrown in between: every frame == the brute-force frame of its parameters, and
+    the frames that may keep the pass do."""
+    from devbuf import DeviceArray
+    tris = mirt.scene_soup(41, 26000, 0.06)
+    rot = np.zeros(9, np.float32); rot[0] = rot[4] = rot[8] = 1
+    W, H = 320, 200
+    mirt.scene_upload(tris)
+    views = [mirt.make_view((0.03 * i, 0.0, -1.7), rot, 160.0, W, H) for i in range(3)]
+    lights = [np.array([[0.1 + 0.05 * j, -0.4, -0.6, 1, 1, 1, 14]], np.float32) for j in range(4)]
+    # (view, light, band, kind): what the stream a frame lands on saw last decides whether its pass is kept
+    seq = [(0, 0, None, "binned")] * 6                      # the light settles into the shared cube; from the second frame of a stream on the pass is kept
+    seq += [(0, 1, None, "binned"), (0, 1, None, "binned"), (0, 2, None, "binned"), (1, 2, None, "binned"), (1, 2, None, "binned"), (1, 2, (40, 120), "binned"),
+            (1, 2, (40, 120), "binned"), (1, 2, None, "binned"), (1, 2, None, "brute"), (1, 2, None, "binned"), (1, 2, None, "binned"), (2, 3, None, "binned"),
+            (2, 3, None, "binned"), (2, 3, None, "binned"), (2, 3, None, "binned"), (2, 3, None, "binned"), (2, 3, None, "binned"), (2, 3, None, "binned"), (0, 3, None, "binned")]
+    want = {}
+    mirt.set_frames_in_flight(1)
+    for v, l, band, _ in seq:
+        if (v, l) not in want:
+            x = DeviceArray((H, W), np.uint32, 0x11)
+            mirt.raytrace_device(views[v], lights[l], (0.2, 0.2, 0.2), mirt.RT_BRUTE, 0, H, 0, x.ptr, W * 4)
+            want[(v, l)] = x.read()
+            x.free()
+    outs = []
+    try:
+        mirt.set_frames_in_flight(in_flight)
+        last = [None] * in_flight                           # what each stream's last binned pass was for: (view, band, lights binned by the frame)
+        reused = kept_possible = 0
+        for i, (v, l, band, kind) in enumerate(seq):
+            x = DeviceArray((H, W), np.uint32, 0x11)
+            outs.append(x)
+            y0, y1 = band if band else (0, H)
+            mirt.raytrace_device(views[v], lights[l], (0.2, 0.2, 0.2), mirt.RT_BINNED if kind == "binned" else mirt.RT_BRUTE, y0, y1, 0, x.ptr, W * 4)
+            st = mirt.stats()                               # (waits for the frame)
+            si = i % in_flight
+            if kind == "binned":
+                assert st["mode_used"] == mirt.RT_BINNED
+                if st["bins_reused"]:
+                    reused += 1
+                    assert last[si] is not None and last[si][:2] == (v, band), "frame %d kept a pass of another view or band" % i
+                else:
+                    assert st["selected_triangles"] > 0
+                last[si] = (v, band)
+            else:
+                assert not st["bins_reused"]
+                last[si] = None                             # the brute-force frame rebuilt the stream's origin rows
+            got = x.read()
+            assert np.array_equal(got[y0:y1], want[(v, l)][y0:y1]), "frame %d (view %d light %d band %s %s): %d words differ" % (
+                i, v, l, band, kind, int((got[y0:y1] != want[(v, l)][y0:y1]).sum()))
+        # the view stands still through most of the sequence: with one frame in flight about a dozen frames start at the trace kernel
+        # (the frame that finds its light unchanged for the fourth time builds the shared cube and runs its pass again)
+        assert reused >= (8 if in_flight == 1 else 2), reused
+    finally:
+        mirt.set_frames_in_flight(1)
+        for x in outs:
+            x.free()
 
 
 # ---- edge cases: tiny / ragged frames and kernel-selection boundaries ----------------------------------
@@ -1090,6 +1157,7 @@ sys.path[:0] = [%r, %r]
 import mirt
 from devbuf import DeviceArray
 mirt.init(0)
+mirt.set_profiling(True)                           # (the binned kernel counts its filter evaluations only for profiled frames)
 L = np.zeros((0, 7), np.float32)                   # no light: camera-only binning passes, nothing else sizes the pair list
 W, H = 320, 200
 tris = mirt.scene_soup(8, 20000, 0.3)           # large triangles: one tile each from afar, dozens of tiles each from close by
@@ -1137,6 +1205,7 @@ sys.path[:0] = [%r, %r]
 import mirt
 from devbuf import DeviceArray
 mirt.init(0)
+mirt.set_profiling(True)                           # (the binned kernel counts its filter evaluations only for profiled frames)
 L = np.array([[0.0, -0.5, -0.7, 1, 1, 1, 14]], np.float32)
 W, H = 320, 200
 tris = mirt.scene_soup(8, 4000, 0.06)

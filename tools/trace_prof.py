@@ -22,8 +22,13 @@ cornell = "cornell" in sys.argv              # BASELINE config 2: the Cornell bo
 mirt.scene_upload(mirt.scene_cornell() if cornell else mirt.scene_soup(2, 1000000, 0.02) if big else mirt.scene_soup(1, 100000, 0.05))
 view = mirt.make_view((0, 0, -3), mirt.rot_from_yaw(0.0, 1.0), float(H), W, H) if cornell else mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.0, 1.0), H / 2.0, W, H)
 x = DeviceArray((H, W), np.uint32)
+move = "move" in sys.argv                   # every frame its own yaw (and a sync behind it): the chain of a single frame, camera moving
 for it in range(12):
+    if move:
+        view = mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.001 * it, 1.0), H / 2.0, W, H)
     mirt.raytrace_device(view, lights, (0.2, 0.2, 0.2), mirt.RT_AUTO if cornell else mirt.RT_BINNED, 0, H, 0, x.ptr, W * 4)
+    if move:
+        mirt.sync()
 mirt.sync()
 print(mirt.stats())
 mirt.shutdown()
