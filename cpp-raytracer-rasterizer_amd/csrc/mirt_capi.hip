@@ -59,6 +59,7 @@ struct RtTraceFrame {                            // (rt_trace.hip)
     uint32_t order_seg;
     const uint32_t *sel;
     const uint32_t *sel_count;
+    int lazy_geo;
 };
 template <bool AA, bool STATS> __global__ void k_rt_trace2(const RtTraceFrame);
 __global__ void k_prep_select(const float *, int, const BinFrameDesc, const SelectOut);
@@ -972,6 +973,10 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.cam_off = cam_off;
     tf.cam_entries = S.d_entries;
     tf.sel = S.d_sel; tf.sel_count = S.d_bin_counters + SEL_COUNT0 + S.sel_parity;
+    // geometry rows staged with every candidate while the scene's tables fit the caches, fetched by the exact stage beyond (rt_trace.hip);
+    // MIRT_LAZY_GEO=0|1 fixes the choice
+    static const int lazy_env = [] { const char *e = getenv("MIRT_LAZY_GEO"); return e ? atoi(e) : -1; }();
+    tf.lazy_geo = lazy_env >= 0 ? (lazy_env != 0) : (g.n >= 400000);
     tf.geo = g.d_geo;
     tf.shade = g.d_shade;
     tf.light_off = transient ? S.d_bin_off + light_key0 : g.lc.d_off;

@@ -457,59 +457,113 @@ __global__ __launch_bounds__(256) void k_raster_resolve(const RasterFrame f)
 // (:549-589) for both pixels in packed FP32, every operand from LDS.  Same arithmetic on the same operands as k_raster_frag +
 // k_raster_resolve, so depthBuffer, pixelColours and the surface come out bit-identical; the frame writes 4 bytes per pixel
 // and reads nothing but the spans.
-constexpr int SMALL_PX = 512;                       // pixels of a row per wave: four passes of 128 (two per lane)
-constexpr int SMALL_ROWS = 4;                       // rows per workgroup = waves per workgroup: every wave works alone on its row
+constexpr int SMALL_PX = 512;                       // pixels of a row per work item: four passes of 128 (two per lane)
+constexpr int SMALL_ROWS = 4;                       // waves per workgroup: every wave works alone, on its own items
 
+// PERSISTENT waves (round 4).  The first version started a wave per (row, 512 pixels): 17 280 short waves at 4K, each beginning with
+// two dependent round trips to memory (the triangle's row bookkeeping, then its span of the row) before its ~760 vector
+// instructions -- the kernel ran at half its issue floor with the waves mostly waiting (SQ_WAIT_INST_ANY > SQ_ACTIVE_INST_ANY).
+// Now the launch holds as many waves as the chip keeps resident (five per SIMD) and a wave takes a contiguous run of items (row, 512
+// pixels), row-major: the per-triangle words (first row, row count, where its spans start, normal, colour) are loaded ONCE per
+// wave; the spans of a row are loaded once per row -- the 512-pixel segments of a row share them.  The kernel alone takes 40 us where
+// it took 43.5; what the change buys shows with frames in flight: the 4K frame went from 38.4 to 31.5 us (the setup kernels of the
+// next frame no longer queue behind 17 000 waves waiting for their first loads).
+// (Requesting the NEXT row's spans before the current row is shaded -- twelve more registers, four waves per SIMD instead of five --
+// measured no better: 43.7 us alone against 40.4 without, 4K Cornell box; kept as a build variant.)
+#ifndef MIRT_SMALL_PREFETCH
+#define MIRT_SMALL_PREFETCH 0
+#endif
 __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
 {
     __shared__ __attribute__((aligned(16))) SmallSpan s_list[SMALL_ROWS][SMALL_MAX_TRIS];
-    const int xbase = (int)blockIdx.x * SMALL_PX;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rr = wave, y = f.y0 + (int)blockIdx.y * SMALL_ROWS + wave;       // this wave's row; no wave waits for another
-    if (y >= f.y1) return;
-    // The spans of row y that draw into [xbase, xbase + SMALL_PX): one lane per triangle.  The lane keeps what the depth test
-    // wants -- first pixel, pixel count, a.zinv, the zinv step -- in its registers (the passes fetch them with v_readlane, triangle
-    // by triangle) and files what the shading wants -- the span's 3-D walk, the triangle's normal and colour -- in the wave's LDS
-    // slice under the triangle's number.  seg_mask[s]: the triangles whose span reaches into the 128 pixels of pass s.
+    const int rr = wave;
+    const int xsegs = (f.W + SMALL_PX - 1) / SMALL_PX, band_rows = f.y1 - f.y0;
+    const int items = xsegs * band_rows;                    // (at most 64 x 32768)
+    const int nwaves = (int)gridDim.x * SMALL_ROWS, gw = (int)blockIdx.x * SMALL_ROWS + wave;
+    const int per = (items + nwaves - 1) / nwaves;
+    const int it0 = gw * per, it1 = min(items, it0 + per);
+    if (it0 >= it1) return;
+    // ---- once per wave: lane t holds what does not depend on the row of triangle t ----
+    int t_r0 = 0, t_rows = 0;
+    size_t t_base = 0;
+    if (lane < f.n) {
+        const TriSetup &st = f.scratch.setup[lane];
+        t_r0 = st.r0; t_rows = st.rows;
+        t_base = f.scratch.row_base[lane];
+        // (a triangle whose rows do not fit the span table was not walked: the frame is incomplete, and mirt_sync says so --
+        // the edge kernels raise the same flag, this one does not rely on them)
+        if (t_rows > 0 && t_base + (size_t)t_rows > f.scratch.cap_rows) { atomicExch(&f.scratch.counters[1], 1u); t_rows = 0; }
+        const float *t15 = f.tris15 + (size_t)15 * lane;
+        float4 *dst = reinterpret_cast<float4 *>(&s_list[rr][lane]);
+        // normal (words 10..12), colour (13..15), triangle (16): rows 2.zw, 3, 4.x of the record; the row's part comes below
+        reinterpret_cast<float *>(dst)[10] = t15[9]; reinterpret_cast<float *>(dst)[11] = t15[10];
+        dst[3] = make_float4(t15[11], t15[12], t15[13], t15[14]);
+        reinterpret_cast<float *>(dst)[16] = __int_as_float(lane);
+    }
+    auto row_has = [&](int y) { return t_rows > 0 && y >= t_r0 && y < t_r0 + t_rows; };
+    auto load_row = [&](int y, float4 &a, float4 &b, float4 &c) {
+        a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); b = a; c = a;        // {ax, dx = 0, ...}: no span in this row
+        if (row_has(y)) {
+            const float4 *src = reinterpret_cast<const float4 *>(f.scratch.spans + t_base + (uint32_t)(y - t_r0));
+            a = src[0]; b = src[1]; c = src[2];                        // {ax, dx, azinv, zstep | ap.xyz, pstep.x | pstep.yz, tri, y}
+        }
+    };
+    const int y_first = f.y0 + it0 / xsegs, y_last = f.y0 + (it1 - 1) / xsegs;
+#if MIRT_SMALL_PREFETCH
+    float4 na, nb, nc;                                                 // the spans of the next row this wave will need
+    load_row(y_first, na, nb, nc);
+#else
+    (void)y_first; (void)y_last;
+#endif
+    const v3p camp = splat3(ld3(f.cam));
+    const bool planes = f.rgb || f.zinv || f.fd || f.index;
+    int row = f.y0 - 1;
     int sp_first = 0, sp_count = 0;             // pixels x = sp_first + i, 0 <= i < sp_count, clipped to x < W (never produced otherwise: :663, E-2)
     float sp_azinv = 0.0f, sp_zstep = 0.0f;
+    bool sp_any = false;
+    for (int it = it0; it < it1; it++) {
+    const int y = f.y0 + it / xsegs, xbase = (it % xsegs) * SMALL_PX;
+    if (y != row) {
+        // ---- once per row: the lane's span of row y into registers (depth test) and LDS (shading); the next row's on its way ----
+        row = y;
+#if MIRT_SMALL_PREFETCH
+        const float4 a = na, b = nb, c = nc;
+        if (y < y_last) load_row(y + 1, na, nb, nc);
+#else
+        float4 a, b, c;
+        load_row(y, a, b, c);
+#endif
+        const int ax = __float_as_int(a.x), dx = __float_as_int(a.y);
+        // fragments are x = ax+1 .. ax+dx (|ax|, dx <= 2^21: RASTER_COORD_LIMIT); those outside [0, W) are never produced
+        sp_first = ax + 1;
+        sp_count = min(dx, f.W - 1 - ax);
+        sp_azinv = a.z; sp_zstep = a.w;
+        sp_any = dx > 0 && sp_count > 0;
+        // (wave-private LDS: the passes of the previous row have read their records)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (sp_any) {
+            // Both ends of the span's walk in the range of the shared-reciprocal division (mirt_math2.hpp: div3p_sel) and no
+            // component changing sign => every pixel between them too: a + step * float(i) is monotone in i, roundings included
+            const float fl = (float)(dx - 1);
+            const float ze = a.z + a.w * fl, xe = b.x + b.w * fl, ye = b.y + c.x * fl, ze3 = b.z + c.y * fl;
+            const bool safe = a.z >= DIV3_LO && a.z < DIV3_HI && ze >= DIV3_LO && ze < DIV3_HI &&
+                              div3_mag_in_range(b.x) && div3_mag_in_range(xe) && (b.x < 0.0f) == (xe < 0.0f) &&
+                              div3_mag_in_range(b.y) && div3_mag_in_range(ye) && (b.y < 0.0f) == (ye < 0.0f) &&
+                              div3_mag_in_range(b.z) && div3_mag_in_range(ze3) && (b.z < 0.0f) == (ze3 < 0.0f);
+            float4 *dst = reinterpret_cast<float4 *>(&s_list[rr][lane]);
+            dst[0] = a; dst[1] = b;
+            reinterpret_cast<float *>(dst)[8] = c.x; reinterpret_cast<float *>(dst)[9] = c.y;     // pstep.yz
+            reinterpret_cast<float *>(dst)[17] = __int_as_float(safe ? 1 : 0);
+        }
+    }
+    // The spans of row y that draw into [xbase, xbase + SMALL_PX): seg_mask[s] = the triangles whose span reaches into the 128
+    // pixels of pass s (the passes fetch the span constants with v_readlane, triangle by triangle).
     unsigned long long seg_mask[SMALL_PX / 128];
     {
-        bool take = false;
-        if (lane < f.n) {
-            const TriSetup &st = f.scratch.setup[lane];
-            const int r0 = st.r0, rows = st.rows;
-            const size_t base = f.scratch.row_base[lane];
-            // (a triangle whose rows do not fit the span table was not walked: the frame is incomplete, and mirt_sync says so --
-            // the edge kernels raise the same flag, this one does not rely on them)
-            if (rows > 0 && base + (size_t)rows > f.scratch.cap_rows) atomicExch(&f.scratch.counters[1], 1u);
-            if (rows > 0 && y >= r0 && y < r0 + rows && base + (size_t)rows <= f.scratch.cap_rows) {
-                const float4 *src = reinterpret_cast<const float4 *>(f.scratch.spans + base + (uint32_t)(y - r0));
-                const float4 a = src[0], b = src[1], c = src[2];      // {ax, dx, azinv, zstep | ap.xyz, pstep.x | pstep.yz, tri, y}
-                const float *t15 = f.tris15 + (size_t)15 * lane;
-                const int ax = __float_as_int(a.x), dx = __float_as_int(a.y);
-                // fragments are x = ax+1 .. ax+dx (|ax|, dx <= 2^21: RASTER_COORD_LIMIT); those outside [0, W) are never produced
-                sp_first = ax + 1;
-                sp_count = min(dx, f.W - 1 - ax);
-                sp_azinv = a.z; sp_zstep = a.w;
-                take = dx > 0 && sp_count > 0 && sp_first + sp_count > xbase && sp_first < xbase + SMALL_PX;
-                if (take) {
-                    // Both ends of the span's walk in the range of the shared-reciprocal division (mirt_math2.hpp: div3p_sel) and no
-                    // component changing sign => every pixel between them too: a + step * float(i) is monotone in i, roundings included
-                    const float fl = (float)(dx - 1);
-                    const float ze = a.z + a.w * fl, xe = b.x + b.w * fl, ye = b.y + c.x * fl, ze3 = b.z + c.y * fl;
-                    const bool safe = a.z >= DIV3_LO && a.z < DIV3_HI && ze >= DIV3_LO && ze < DIV3_HI &&
-                                      div3_mag_in_range(b.x) && div3_mag_in_range(xe) && (b.x < 0.0f) == (xe < 0.0f) &&
-                                      div3_mag_in_range(b.y) && div3_mag_in_range(ye) && (b.y < 0.0f) == (ye < 0.0f) &&
-                                      div3_mag_in_range(b.z) && div3_mag_in_range(ze3) && (b.z < 0.0f) == (ze3 < 0.0f);
-                    float4 *dst = reinterpret_cast<float4 *>(&s_list[rr][lane]);
-                    dst[0] = a; dst[1] = b;
-                    dst[2] = make_float4(c.x, c.y, t15[9], t15[10]);          // pstep.yz, normal.xy
-                    dst[3] = make_float4(t15[11], t15[12], t15[13], t15[14]);    // normal.z, colour
-                    dst[4] = make_float4(__int_as_float(lane), __int_as_float(safe ? 1 : 0), 0.0f, 0.0f);
-                }
-            }
-        }
+        const bool take = sp_any && sp_first + sp_count > xbase && sp_first < xbase + SMALL_PX;
 #pragma unroll
         for (int seg = 0; seg < SMALL_PX / 128; seg++)
             seg_mask[seg] = __builtin_amdgcn_ballot_w64(take && sp_first + sp_count > xbase + seg * 128 && sp_first < xbase + seg * 128 + 128);
@@ -518,8 +572,7 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    const v3p camp = splat3(ld3(f.cam));
-    const bool planes = f.rgb || f.zinv || f.fd || f.index;
+
 #pragma unroll
     for (int seg = 0; seg < SMALL_PX / 128; seg++) {
         // the lane's two pixels are neighbours: both inside or both outside a surface almost always, so a pass whose pixels
@@ -612,6 +665,7 @@ __global__ __launch_bounds__(256) void k_raster_small(const RasterFrame f)
         if (ok1 && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0) *reinterpret_cast<uint2 *>(dst) = make_uint2(word[0], word[1]);
         else { if (ok0) dst[0] = word[0]; if (ok1) dst[1] = word[1]; }
     }
+    }                                                       // (items of this wave)
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
@@ -759,7 +813,13 @@ int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipS
     // Scenes of at most 64 triangles: one kernel does the depth test in registers and shades (no key buffer, no atomics).
     if (small) {
         begin(MIRT_K_RASTER_RESOLVE);
-        hipLaunchKernelGGL(k_raster_small, dim3((f.W + SMALL_PX - 1) / SMALL_PX, (band_rows + SMALL_ROWS - 1) / SMALL_ROWS), dim3(256), 0, stream, f);
+        // persistent waves: as many as stay resident (five per SIMD; MIRT_SMALL_WGS_PER_CU for A/B runs), each with a contiguous run of
+        // (row, 512-pixel) items
+        static const int cus = [] { int dev = 0; hipDeviceProp_t p; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }();
+        const long long items = (long long)((f.W + SMALL_PX - 1) / SMALL_PX) * band_rows;
+        static const int per_cu = [] { const char *e = getenv("MIRT_SMALL_WGS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : 5; }();
+        const unsigned wgs = (unsigned)std::max<long long>(1, std::min<long long>((items + SMALL_ROWS - 1) / SMALL_ROWS, (long long)cus * per_cu));
+        hipLaunchKernelGGL(k_raster_small, dim3(wgs), dim3(256), 0, stream, f);
         end(MIRT_K_RASTER_RESOLVE);
         if (hipGetLastError() != hipSuccess) return MIRT_ERR_HIP;
         return MIRT_OK;

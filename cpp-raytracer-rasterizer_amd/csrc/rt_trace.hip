@@ -128,7 +128,7 @@ __device__ __forceinline__ void wave_lds_fence()
 // trip inside the drain (their queue never outlives the staged chunk).
 template <bool SHADOW>
 __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, const float4 *__restrict__ geo, v3 start,
-                                         const uint32_t *__restrict__ row_tri = nullptr)
+                                         const uint32_t *__restrict__ row_tri = nullptr, bool lazy_geo = false)
 {
     wave_lds_fence();
     if (lane < count) {
@@ -142,6 +142,10 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
                 const uint32_t tri = row_tri ? row_tri[a.y] : a.y;         // (a.y = the candidate's row; the origin tables' rows are the triangles)
                 const float4 *g = geo + (size_t)tri * 3;
                 g0 = g[0]; g1 = g[1]; g2 = g[2];
+            } else if (lazy_geo) {
+                const float4 *g = geo + (size_t)a.y * 3;                   // (a.y = the triangle)
+                g0 = g[0]; g1 = g[1]; g2 = g[2];
+                a.x &= 0xFFu;
             } else {
                 const float4 *g = s.geo + (a.x >> 8) * 3;
                 g0 = g[0]; g1 = g[1]; g2 = g[2];
@@ -169,9 +173,9 @@ __device__ __forceinline__ void tr_drain(TrWaveLds &s, int lane, int count, cons
 // Drains TR_DRAIN pairs and moves the rest of the queue to its front.
 template <bool SHADOW>
 __device__ __forceinline__ void tr_drain_full(TrWaveLds &s, int lane, int &qn, const float4 *__restrict__ geo, v3 start,
-                                              const uint32_t *__restrict__ row_tri = nullptr)
+                                              const uint32_t *__restrict__ row_tri = nullptr, bool lazy_geo = false)
 {
-    tr_drain<SHADOW>(s, lane, TR_DRAIN, geo, start, row_tri);
+    tr_drain<SHADOW>(s, lane, TR_DRAIN, geo, start, row_tri, lazy_geo);
     const int rest = qn - TR_DRAIN;
     float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint2 a = make_uint2(0u, 0u);
@@ -253,6 +257,8 @@ struct RtTraceFrame {
     uint32_t order_seg;               // room per segment = the most pairs a group can have = waves per group
     const uint32_t *sel;              // the triangles k_prep_select found the frame may see, and how many: what a frame that fell
     const uint32_t *sel_count;        // back to brute force walks (their origin rows are the ones the frame has built)
+    int lazy_geo;                     // 1: geometry rows are fetched by the exact stage, for the pairs it accepts, instead of being staged
+                                      // with every candidate (scenes whose tables no longer fit the caches: see the staging code)
 };
 
 // One wave renders one PAIR of horizontally adjacent tiles.  Two things decide which wave takes which pair:
@@ -368,6 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
     const uint32_t nA = brute ? nall : rec.nA, nB = brute ? (enB ? nall : 0u) : rec.nB;
     const uint32_t nmax = max(nA, nB);
     const float4 *geo4 = reinterpret_cast<const float4 *>(tf.geo);
+    const bool lazy = tf.lazy_geo != 0;
     TM_SEG(0)
 
     float bdA = FLT_MAX, bdB = FLT_MAX;                    // Update() reset (:335-339), once per frame
@@ -411,9 +418,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     const uint32_t idx = brute ? tf.sel[base + (uint32_t)sj] : tf.cam_entries[(sh ? begB : begA) + base + (uint32_t)sj];
                     const float4 *src = reinterpret_cast<const float4 *>(f.cam_tab + idx);
                     const float4 a0 = src[0], a1 = src[1], a2 = src[2];
-                    const float4 *gsrc = geo4 + (size_t)idx * 3;
-                    float4 *gdst = s.geo + lane * 3;
-                    gdst[0] = gsrc[0]; gdst[1] = gsrc[1]; gdst[2] = gsrc[2];
+                    // the candidate's geometry row beside it -- what the exact stage needs for the hit point of an ACCEPTED pair, under
+                    // one in a hundred of the candidates -- so that the drain makes no round trip to memory: right while the tables
+                    // sit in the caches (100 k triangles: 9.6 MB), half of all the kernel fetches once they do not (1 M triangles at
+                    // 8K: 96 MB of rows, 1.7 GB fetched per launch, L2 hit rate 0.44): there the drain fetches the few rows it wants
+                    if (!lazy) {
+                        const float4 *gsrc = geo4 + (size_t)idx * 3;
+                        float4 *gdst = s.geo + lane * 3;
+                        gdst[0] = gsrc[0]; gdst[1] = gsrc[1]; gdst[2] = gsrc[2];
+                    }
                     float *dst = reinterpret_cast<float *>(s.rows) + sj * 24 + sh;
                     dst[0] = a0.x; dst[2] = a0.y; dst[4] = a0.z; dst[6] = a0.w;
                     dst[8] = a1.x; dst[10] = a1.y; dst[12] = a1.z; dst[14] = a1.w;
@@ -456,14 +469,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                         bool passA = passA0;
                         if (qn + cA + cB > TR_QUEUE) {                             // (rare: no room for this step)
                             TM_SEG(2)
-                            if (qn) { tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; if (STATS) ndrains++; }
+                            if (qn) { tr_drain<false>(s, lane, qn, geo4, cam, nullptr, lazy); qn = 0; if (STATS) ndrains++; }
                             if (cA + cB > TR_QUEUE) {                              // the step alone does not fit: tile A's pairs go first
                                 if (passA) {
                                     const int at = wave_rank(mA);
                                     s.q[at] = make_float4(td.den.x, td.pu.x, td.qv.x, R1.z);
                                     s.qa[at] = make_uint2((uint32_t)lane | ((uint32_t)j << 8), __float_as_uint(R5.z));
                                 }
-                                tr_drain<false>(s, lane, cA, geo4, cam); if (STATS) ndrains++;
+                                tr_drain<false>(s, lane, cA, geo4, cam, nullptr, lazy); if (STATS) ndrains++;
                                 passA = false; cA = 0;
                             }
                             TM_SEG(3)
@@ -481,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                         qn += cA + cB;
                         if (qn >= TR_DRAIN) {
                             TM_SEG(2)
-                            do { tr_drain_full<false>(s, lane, qn, geo4, cam); if (STATS) ndrains++; } while (qn >= TR_DRAIN);
+                            do { tr_drain_full<false>(s, lane, qn, geo4, cam, nullptr, lazy); if (STATS) ndrains++; } while (qn >= TR_DRAIN);
                             TM_SEG(3)
                             lbA = okA ? min_t_dist(s.best[lane]) : lbA; lbB = okB ? min_t_dist(s.best[lane + 64]) : lbB;
                             tbA = wave_max_f(lbA); tbB = wave_max_f(lbB);
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                 // the records they leave prune the next chunk
                 TM_SEG(2)
                 if (qn) {
-                    tr_drain<false>(s, lane, qn, geo4, cam); qn = 0; if (STATS) ndrains++;
+                    tr_drain<false>(s, lane, qn, geo4, cam, nullptr, lazy); qn = 0; if (STATS) ndrains++;
                     if (base + TR_STAGE < nmax) {
                         lbA = okA ? min_t_dist(s.best[lane]) : lbA; lbB = okB ? min_t_dist(s.best[lane + 64]) : lbB;
                         tbA = wave_max_f(lbA); tbB = wave_max_f(lbB);

@@ -11,6 +11,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), os.path.join(ROOT, "tests")]
 import mirt                                 # noqa: E402
+for a in sys.argv[1:]:
+    if a.endswith(".so"):
+        mirt.LIB_PATH = a                   # an A/B build (tools/build_variant.sh)
 from devbuf import DeviceArray              # noqa: E402
 
 W, H = 7680, 4320
