@@ -63,6 +63,7 @@ struct RtTraceFrame {                            // (rt_trace.hip)
 };
 template <bool AA, bool STATS> __global__ void k_rt_trace2(const RtTraceFrame);
 __global__ void k_prep_select(const float *, int, const BinFrameDesc, const SelectOut);
+__global__ void k_select_faces(const float *, int, const float *, const BinFrameDesc *, OriginRow *, uint32_t *, uint32_t, uint32_t *);
 __global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *, uint32_t);
 __global__ void k_geo_table(const float *, int, GeoRow *, ShadeRow *);
 __global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t,
@@ -146,6 +147,7 @@ struct RtScratch {
     uint32_t *h_count = nullptr;                 // pinned
     hipEvent_t ev_count = nullptr;
     bool count_pending = false;
+    bool count_event_due = false;                // bin_pass published a count: the caller records ev_count behind the frame's last kernel
     bool have_known = false;
     uint32_t known_pairs = 0;
     uint32_t cap_bins = 0, cap_entries = 0;
@@ -166,6 +168,11 @@ struct RtScratch {
     uint32_t *d_sel = nullptr;
     int sel_n = 0;
     int sel_parity = 0;
+    // k_select_faces: per face of the light cubes this stream bins (its own frames' moving lights, or the shared cube's build) the
+    // triangles the face can see -- list i at d_face_sel + i * n -- and the lists' lengths
+    uint32_t *d_face_sel = nullptr;
+    size_t cap_face_sel = 0;                     // slots
+    uint32_t *d_face_counts = nullptr;           // 6 * MIRT_MAX_LIGHTS words
     // the cost histogram of the whole frame (weighted partition): device words, and where they travel for the host to read --
     // HIST_RING pinned copies taken in turn, an event behind each
     uint32_t *d_hist = nullptr;
@@ -577,10 +584,9 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     HIP_TRY(bucket_sort_pairs(S.d_pair_keys, S.d_pair_vals, counter, S.cap_used, *npairs, bs.nbins, S.d_sorted_keys, S.d_tmp_vals,
                               bcnt, bbase, bcur, bin_off, S.d_entries, g.cu_count, g.stream, count_out));
     S.bucket_dirty = false;                                  // k_bs_local leaves the counts and cursors zero
-    if (publish_count) {
-        HIP_TRY(hipEventRecord(S.ev_count, g.stream));
-        S.count_pending = true;
-    }
+    // (the event that tells a later frame the count has landed is recorded by the caller BEHIND the frame's trace kernel: an event
+    // record between two kernels of the chain is a barrier packet of its own, ~5 us of the single frame's latency)
+    if (publish_count) S.count_event_due = true;
     return MIRT_OK;
 }
 
@@ -649,6 +655,24 @@ int light_shells_for(int nlights, int cube_bins, uint32_t keys_in_front)
     return ns;
 }
 
+// Room for the face lists of `nlights` light cubes (k_select_faces); the stream must be idle when they grow.
+int ensure_face_lists(RtScratch &S, int nlights)
+{
+    int rc;
+    if (!S.d_face_counts) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_face_counts), sizeof(uint32_t) * 6 * MIRT_MAX_LIGHTS));
+        HIP_TRY(hipMemsetAsync(S.d_face_counts, 0, sizeof(uint32_t) * 6 * MIRT_MAX_LIGHTS, g.stream));
+    }
+    const size_t want = (size_t)6 * (size_t)nlights * (size_t)g.n;
+    if (want > S.cap_face_sel) {
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        S.cap_face_sel = 0;
+        if ((rc = dev_realloc(&S.d_face_sel, want))) return rc;
+        S.cap_face_sel = want;
+    }
+    return MIRT_OK;
+}
+
 // The SHARED light-cube bins and their expanded rows, for lights that stand still: built on g.stream as a barrier call -- the
 // frames of both streams read the tables -- whenever the scene, a light position or the grid differs from what is held.  (Lights
 // that just moved do not come here: rt_enqueue_binned bins their cubes together with the camera frame, on the frame's own stream.)
@@ -687,14 +711,19 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
         fill_light_frames(frames, f, nlights, cube_bins, shells, 0u);
         HIP_TRY(upload_small(C.d_frames, frames, sizeof(BinFrameDesc) * 6 * nlights, g.stream));
         HIP_TRY(upload_small(C.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
-        hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, nlights), dim3(256), 0, g.stream,
-                           g.d_tris, g.n, C.d_origins, V3(0.0f, 0.0f, 0.0f), 1, (OriginRow *)nullptr, C.d_light_tab, (uint32_t *)nullptr,
-                           (unsigned long long *)nullptr, C.d_counter);
+        // the lights' origin rows, and per face the triangles it can see (k_select_faces); the build's pair counter is zeroed on the way
+        if ((rc = ensure_face_lists(S, nlights))) return rc;
+        HIP_TRY(hipMemsetAsync(S.d_face_counts, 0, sizeof(uint32_t) * 6 * nlights, g.stream));
+        HIP_TRY(hipMemsetAsync(C.d_counter, 0, 512, g.stream));
+        hipLaunchKernelGGL(k_select_faces, dim3((unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count), nlights), dim3(1024), 0, g.stream,
+                           g.d_tris, g.n, C.d_origins, C.d_frames, C.d_light_tab, S.d_face_sel, (uint32_t)g.n, S.d_face_counts);
         BinSet bs;
         memset(&bs, 0, sizeof bs);
         bs.frames = C.d_frames; bs.nframes = 6 * nlights; bs.nbins = nkeys; bs.bin_off = C.d_off;
+        bs.face_lists = S.d_face_sel; bs.face_counts = S.d_face_counts; bs.face_stride = (uint32_t)g.n;
         uint32_t npairs = 0;
         if ((rc = bin_pass(S, bs, nullptr, C.d_light_tab, C.d_counter, C.d_off, true, &npairs))) return rc;
+        S.count_event_due = false;                           // (a fresh pass without a guess reads its count back: nothing was published)
         if (npairs > C.cap_rows) {
             C.cap_rows = 0;
             if ((rc = dev_realloc(&C.d_rows, (size_t)npairs + npairs / 8 + 1024))) return rc;
@@ -907,6 +936,10 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         so.cam_tab = S.d_cam_tab; so.sel = S.d_sel;
         so.sel_count = S.d_bin_counters + SEL_COUNT0 + S.sel_parity; so.sel_count_next = S.d_bin_counters + SEL_COUNT0 + (S.sel_parity ^ 1);
         so.zero_hits = g.d_hits; so.zero_counter = S.d_bin_counters;
+        if (transient) {
+            if ((rc = ensure_face_lists(S, nlights))) return rc;
+            so.zero_faces = S.d_face_counts; so.zero_faces_n = 6 * nlights;
+        }
         if ((rc = hist_prepare(S, bs.frame0, key, &so))) return rc;
         // one workgroup of 1024 threads per CU: a workgroup reserves its slice of the list with ONE atomic (rt_binned.hip)
         const unsigned sel_grid = (unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count);
@@ -929,10 +962,11 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
             HIP_TRY(upload_small(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), g.stream));
             HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
             bs.frames = S.d_frames; bs.nframes = 1 + 6 * nlights;
-            // origin rows of every light (all triangles: a light cube sees the whole scene)
-            hipLaunchKernelGGL(k_prep_origin, dim3((g.n + 255) / 256, nlights), dim3(256), 0, g.stream,
-                               g.d_tris, g.n, S.d_origins, V3(0.0f, 0.0f, 0.0f), 1, (OriginRow *)nullptr, S.d_light_tab,
-                               (uint32_t *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr);
+            // origin rows of every light (all triangles: a shadow ray of a frame that falls back to brute force walks them all) and,
+            // per cube face, the list of the triangles it can see (k_prep_select above has zeroed the lists' counters)
+            hipLaunchKernelGGL(k_select_faces, dim3((unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count), nlights), dim3(1024), 0, g.stream,
+                               g.d_tris, g.n, S.d_origins, S.d_frames + 1, S.d_light_tab, S.d_face_sel, (uint32_t)g.n, S.d_face_counts);
+            bs.face_lists = S.d_face_sel; bs.face_counts = S.d_face_counts; bs.face_stride = (uint32_t)g.n;
         }
         if ((rc = bin_pass(S, bs, S.d_cam_tab, transient ? S.d_light_tab : nullptr, S.d_bin_counters, S.d_bin_off, true, &S.bin_entries, may_guess))) return rc;
         S.last_bin_mode = bin_mode;
@@ -1006,6 +1040,11 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     }
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
+    if (S.count_event_due) {
+        S.count_event_due = false;
+        HIP_TRY(hipEventRecord(S.ev_count, g.stream));
+        S.count_pending = true;
+    }
     call_end();
     return MIRT_OK;
 }
@@ -1377,6 +1416,8 @@ extern "C" void mirt_shutdown(void)
     for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }
     for (RtScratch &S : g.rt) {
         if (S.d_sel) (void)hipFree(S.d_sel);
+        if (S.d_face_sel) (void)hipFree(S.d_face_sel);
+        if (S.d_face_counts) (void)hipFree(S.d_face_counts);
         if (S.d_hist) (void)hipFree(S.d_hist);
         if (S.h_hist) (void)hipHostFree(S.h_hist);
         for (hipEvent_t e : S.ev_hist) if (e) (void)hipEventDestroy(e);

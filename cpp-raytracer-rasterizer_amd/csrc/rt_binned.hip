@@ -214,6 +214,7 @@ __global__ __launch_bounds__(SEL_WG) void k_prep_select(const float *__restrict_
             for (int g = threadIdx.x; g < HIT_SHARDS * HIT_SHARD_STRIDE; g += SEL_WG) out.zero_hits[g] = 0ull;
         if (out.zero_counter && (threadIdx.x == 0 || (threadIdx.x >= 16 && threadIdx.x < 80))) out.zero_counter[threadIdx.x] = 0u;
         if (threadIdx.x == 0) *out.sel_count_next = 0u;
+        if (out.zero_faces && (int)threadIdx.x < out.zero_faces_n) out.zero_faces[threadIdx.x] = 0u;
     }
     if (out.hist && threadIdx.x < SEL_HIST_MAX) s_hist[threadIdx.x] = 0u;
     if (threadIdx.x == 0) s_fill = 0u;
@@ -276,6 +277,74 @@ __global__ __launch_bounds__(SEL_WG) void k_prep_select(const float *__restrict_
     }
 }
 
+// ---- k_select_faces: the lights' origin rows, and per cube face the triangles it can see ---------------------------------------
+// A light's cube has six faces and a triangle lies in front of three of them and projects into one, give or take: binning every
+// triangle for every face ran the thousand-instruction set-up six times per (triangle, light) to find five of them empty.  This
+// kernel -- it takes over k_prep_origin's work for the lights of a frame that bins its own cubes, and of the shared cube's build --
+// writes the origin row of (triangle, light) and puts the triangle on the list of every face frame_may_see does not rule out
+// (rt_binned.hpp: clearly behind the face's plane and far from degenerate, or clearly in front and outside the face's square);
+// k_bin_pairs walks the lists.  grid.y = light, a workgroup of 1024 threads strides over the triangles; kept indices are staged
+// per face in LDS and leave with one atomic per (workgroup, face, hand-over).  face_counts: zero on entry (k_prep_select zeroes
+// them for a frame; the cube build fills them itself).
+constexpr int FACE_STAGE = 2048;                      // indices per face a workgroup stages between hand-overs (6 x 8 KiB)
+__global__ __launch_bounds__(SEL_WG) void k_select_faces(const float *__restrict__ tris15, int n, const float *__restrict__ origins /* (1 + nl) x 3 */,
+                                                        const BinFrameDesc *__restrict__ faces /* 6 per light */, OriginRow *__restrict__ light_tab,
+                                                        uint32_t *__restrict__ lists, uint32_t stride, uint32_t *__restrict__ face_counts)
+{
+    __shared__ uint32_t s_sel[6][FACE_STAGE];
+    __shared__ uint32_t s_fill[6], s_base[6];
+    const int lane = threadIdx.x & 63, k = (int)blockIdx.y;
+    if (threadIdx.x < 6) s_fill[threadIdx.x] = 0u;
+    __syncthreads();
+    const v3 S = ld3(origins + 3 * (1 + k));
+    const int nchunks = (n + SEL_WG - 1) / SEL_WG;
+    auto flush = [&]() {
+        __syncthreads();
+        if (threadIdx.x < 6 && s_fill[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&face_counts[k * 6 + (int)threadIdx.x], s_fill[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+            const uint32_t staged = s_fill[f], base = s_base[f];
+            uint32_t *dst = lists + (size_t)(k * 6 + f) * stride + base;
+            for (uint32_t i = threadIdx.x; i < staged; i += SEL_WG) dst[i] = s_sel[f][i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) s_fill[threadIdx.x] = 0u;
+        __syncthreads();
+    };
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        uint32_t most = 0;
+#pragma unroll
+        for (int f = 0; f < 6; f++) most = max(most, s_fill[f]);
+        if (most + (uint32_t)SEL_WG > (uint32_t)FACE_STAGE) flush();        // (uniform: the fills only change between the barriers below)
+        const int i = c * SEL_WG + (int)threadIdx.x;
+        uint32_t keep = 0;
+        if (i < n) {
+            const float *t15 = tris15 + (size_t)15 * i;
+            const OriginRow r = make_origin_row(t15, S);
+            light_tab[(size_t)k * n + i] = r;
+            const v3 va = ld3(t15), vb = ld3(t15 + 3), vc = ld3(t15 + 6);
+            for (int f = 0; f < 6; f++) {
+                PreBox box;
+                bool boxed;
+                if (frame_may_see(r, va, vb, vc, faces[k * 6 + f], &box, &boxed)) keep |= 1u << f;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 6; f++) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64((keep >> f) & 1u);
+            if (m) {
+                uint32_t at0 = 0;
+                if (lane == 0) at0 = atomicAdd(&s_fill[f], (uint32_t)__popcll(m));
+                at0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)at0);
+                if ((keep >> f) & 1u) s_sel[f][at0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            }
+        }
+        __syncthreads();
+    }
+    flush();
+}
+
 // What the flattened bin-by-bin tests need of a direct item, in LDS: A2, Bu, Bv and box = {lou, hiu, lov, hiv}, one array per
 // field (neighbouring lanes read neighbouring items: 16-byte stride, where a 64-byte record put them on the same banks).
 
@@ -306,8 +375,21 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
     // serial ~10 us of set-up) goes in items of 64: the set-up of an item then occupies one wave, its flattened tests still all eight
     const int cam_chunk = (listed && nsel < 32768u) ? 64 : chunk_tris;
     const int ncam = listed ? (int)((nsel + (uint32_t)cam_chunk - 1u) / (uint32_t)cam_chunk) : 0;
+    // The other frames -- the light-cube faces -- each walk the scene, or, when k_select_faces has listed what each face can see
+    // (bs.face_lists), their lists: s_first[f] = the first work item of face frame f (items of chunk_tris triangles), an exclusive
+    // prefix over at most MAX_BIN_FRAMES frames, computed by every workgroup for itself.
     const int nrest = listed ? bs.nframes - 1 : bs.nframes;
-    const int nwork = ncam + nchunks * nrest;
+    const bool faces_listed = bs.face_lists != nullptr;
+    __shared__ uint32_t s_first[MAX_BIN_FRAMES + 1];
+    if (faces_listed) {
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int ff = 0; ff < nrest; ff++) { s_first[ff] = run; run += (min(bs.face_counts[ff], (uint32_t)n) + (uint32_t)chunk_tris - 1u) / (uint32_t)chunk_tris; }
+            s_first[nrest] = run;
+        }
+        __syncthreads();
+    }
+    const int nwork = ncam + (faces_listed ? (int)s_first[nrest] : nchunks * nrest);
     if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
     if (bs.bucket_cnt)
         for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += BIN_WG) s_bucket[b] = 0u;
@@ -347,13 +429,22 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
         st_t = __builtin_amdgcn_s_memtime();
 #endif
         int chunk, frame;
-        if (w < ncam) { chunk = w; frame = 0; }
-        else { const int w2 = w - ncam; chunk = w2 / nrest; frame = w2 - chunk * nrest + (listed ? 1 : 0); }
-        const bool from_list = w < ncam;
-        const int item_tris = from_list ? cam_chunk : chunk_tris;
-        const uint32_t slot = (uint32_t)chunk * (uint32_t)item_tris + threadIdx.x;       // place in the list (camera frame) or in the scene
-        const uint32_t nhere = from_list ? nsel : (uint32_t)n;
-        const uint32_t tri = ((int)threadIdx.x < item_tris && slot < nhere) ? (from_list ? bs.sel[slot] : slot) : 0xFFFFFFFFu;
+        const uint32_t *list = nullptr;                   // the item's triangles: a chunk of this list, or of the scene
+        uint32_t nhere = (uint32_t)n;
+        const bool from_cam_list = w < ncam;
+        if (from_cam_list) { chunk = w; frame = 0; list = bs.sel; nhere = nsel; }
+        else if (faces_listed) {
+            const uint32_t w2 = (uint32_t)(w - ncam);
+            int lo = 0, hi = nrest;                       // the face frame whose items [s_first[f], s_first[f + 1]) hold w2
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_first[mid] <= w2) lo = mid; else hi = mid; }
+            chunk = (int)(w2 - s_first[lo]);
+            frame = lo + (listed ? 1 : 0);
+            list = bs.face_lists + (size_t)lo * bs.face_stride;
+            nhere = min(bs.face_counts[lo], (uint32_t)n);
+        } else { const int w2 = w - ncam; chunk = w2 / nrest; frame = w2 - chunk * nrest + (listed ? 1 : 0); }
+        const int item_tris = from_cam_list ? cam_chunk : chunk_tris;
+        const uint32_t slot = (uint32_t)chunk * (uint32_t)item_tris + threadIdx.x;       // place in the list or in the scene
+        const uint32_t tri = ((int)threadIdx.x < item_tris && slot < nhere) ? (list ? list[slot] : slot) : 0xFFFFFFFFu;
         const BinFrameDesc fr = bs.frames ? bs.frames[frame] : bs.frame0;
         BinFrameGrid gr;
         gr.nbu = fr.nbu; gr.fj0 = fr.j0; gr.fj1 = fr.j1; gr.fbase = fr.base; gr.nshell = (uint32_t)max(fr.nshell, 1);

@@ -91,6 +91,11 @@ struct BinSet {
     // whose origin table is the camera's (tab == 0) walk this list instead of the scene
     const uint32_t *sel;
     const uint32_t *sel_count;
+    // ... and the light-cube faces' (k_select_faces): the i-th frame that is not the listed camera frame walks face list i --
+    // face_counts[i] triangle indices at face_lists + i * face_stride (nullable: every triangle for every face)
+    const uint32_t *face_lists;
+    const uint32_t *face_counts;
+    uint32_t face_stride;
 };
 
 // What k_prep_select leaves behind for the frame's other kernels, per stream.
@@ -102,6 +107,8 @@ struct SelectOut {
     uint32_t *sel_count_next;     // the counter the NEXT pass will use: zeroed here
     uint32_t *hist;               // nullable: SEL_HIST_MAX words, += estimated (tile, triangle) pairs per coarse tile row of the WHOLE frame
     int hist_shift;
+    uint32_t *zero_faces;            // nullable: the face lists' counters of this frame's light cubes (k_select_faces), zero_faces_n words
+    int zero_faces_n;
     unsigned long long *zero_hits;   // nullable: the frame's hit counters (k_prep_origin's duty as first kernel of a frame)
     uint32_t *zero_counter;          // nullable: the binning pass's counters: [0] and [16..79] are zeroed
 };
@@ -245,7 +252,10 @@ __device__ __forceinline__ void add_bbox(TriBinFns &t, const float *t15, const B
 // whose rows and columns it misses (by a whole bin more than add_bbox()'s own conversion would ask for) holds no pair of the
 // triangle.  Reciprocals and reciprocal square roots are the hardware's one-ulp approximations; the projection's pad carries
 // 2^-21 per quotient instead of add_bbox()'s 2^-22 for them, margin distances and the displacement are raised by 2^-19.
-// Everything else -- a vertex near or behind the plane, a vanishing area, an origin in the triangle's plane (|e1e2b| below the
+// A triangle whose three vertices lie clearly BEHIND the plane -- what five of the six faces of a light's cube see of most triangles
+// -- cannot be hit at all while d stays below half its projected inradius (add_bbox's BOX_EMPTY, with the inradius bounded from
+// below by area_lo over the box's perimeter).
+// Everything else -- a vertex near the plane, a vanishing area, an origin in the triangle's plane (|e1e2b| below the
 // threshold k_bin_pairs uses for "either sign"), any NaN -- answers "may be seen" and leaves the decision to the full set-up.
 // Returns false only when NO ray of rows [j0, j1) x columns [0, nbu) of the frame can be accepted on the triangle; *boxed says
 // whether the box outputs (bin-index ranges over the whole grid, unclamped floats) are valid -- the cost histogram uses them.
@@ -257,13 +267,14 @@ __device__ __forceinline__ bool frame_may_see(const OriginRow &row, v3 va, v3 vb
     if (!(fabsf(nbv) >= 1.6940658945086007e-21f)) return true;            // either sign of e1e2d may pass t >= 0 (k_bin_pairs: `both`); also NaN
     const v3 vert[3] = { va, vb, vc };
     float us[3], vs[3], pad = 0.0f;
-    int front = 0;
+    int front = 0, behind = 0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const float gx = fr.S[0] - vert[j].x, gy = fr.S[1] - vert[j].y, gz = fr.S[2] - vert[j].z;
         const float w = fr.rw[0] * gx + fr.rw[1] * gy + fr.rw[2] * gz;
         const float wm = fabsf(fr.rw[0] * gx) + fabsf(fr.rw[1] * gy) + fabsf(fr.rw[2] * gz);
         front += (w > 0.00390625f * wm);
+        behind += (w < -0.00390625f * wm);
         const float un = fr.ru[0] * gx + fr.ru[1] * gy + fr.ru[2] * gz, vn = fr.rv[0] * gx + fr.rv[1] * gy + fr.rv[2] * gz;
         const float um = fabsf(fr.ru[0] * gx) + fabsf(fr.ru[1] * gy) + fabsf(fr.ru[2] * gz);
         const float vm = fabsf(fr.rv[0] * gx) + fabsf(fr.rv[1] * gy) + fabsf(fr.rv[2] * gz);
@@ -273,7 +284,7 @@ __device__ __forceinline__ bool frame_may_see(const OriginRow &row, v3 va, v3 vb
         pad = fmaxf(pad, 4.76837158203125e-07f * ((um + fabsf(us[j]) * wm) * aiw + (vm + fabsf(vs[j]) * wm) * aiw) +
                              4.76837158203125e-07f * (fabsf(us[j]) + fabsf(vs[j])));
     }
-    if (front != 3) return true;
+    if (front != 3 && behind != 3) return true;
     // margin distances of the three edge functions p, q, s = n - p - q (make_edge_fn / make_bin_fns: same gradients, same margins)
     float cu[3], cv[3], mg[3];
     const float4 rr[3] = { row.r0, row.r1, row.r2 };
@@ -297,6 +308,13 @@ __device__ __forceinline__ bool frame_may_see(const OriginRow &row, v3 va, v3 vb
     // a triangle is at most that of its box) and the cross product cancels (2^-21 of its two products)
     const float area_lo = fabsf(t1 - t2) - 4.0f * pad * (extu + extv) - 4.76837158203125e-07f * (fabsf(t1) + fabsf(t2));
     if (!(area_lo > 0.0f)) return true;                                    // (also NaN)
+    if (behind == 3) {
+        // all three vertices clearly BEHIND the projection plane (five of the six faces of a light's cube see most triangles so):
+        // the projected lines bound the antipodal triangle, inside which the three functions have the rejecting sign; a point within
+        // margin of all three accepting sides needs d >= r_in (add_bbox).  r_in from below: the area from below over the perimeter
+        // from above (that of the box); half of that is the threshold, as there.  Otherwise: the full set-up decides.
+        return !(d < 0.5f * (area_lo * __builtin_amdgcn_rcpf(2.0f * (extu + extv)) * 0.99999809265136719f));
+    }
     const float disp = (2.5f * d) * (extu * extu + extv * extv) * __builtin_amdgcn_rcpf(area_lo) * 1.0000019073486328125f;
     const float slack = 2.0f * pad + 1.0e-6f * fmaxf(extu, extv);
     const float bu0 = u0 - disp - slack, bu1 = u1 + disp + slack, bv0 = v0 - disp - slack, bv1 = v1 + disp + slack;

@@ -74,7 +74,8 @@ typedef enum mirt_rt_mode {
 typedef struct mirt_stats {
     uint64_t primary_rays;        /* width * rows rendered                                          */
     uint64_t shadow_rays;         /* nlights * (pixels whose primary ray hit)                       */
-    uint64_t tests;               /* ray-triangle tests actually executed (0 if not counted)        */
+    uint64_t tests;               /* ray-triangle tests actually executed (0 if not counted: the binned kernel keeps this and
+                                     the four counts below for frames rendered with mirt_set_profiling(1) only)          */
     float gpu_ms;                 /* hipEvent time of the call's device work; 0 unless profiling is on   */
     float kernel_ms[8];           /* per-kernel time of the call when profiling is on (see below)    */
     int32_t mode_used;            /* mirt_rt_mode actually used                                      */
