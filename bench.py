@@ -51,7 +51,7 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: vector FP32 peak (counts FM
 PEAK_REACHABLE_TFLOPS = {"no_fma_packed": 78.6, "no_fma_scalar": 39.3}
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 ISSUE_CEILING = 0.24          # measured VALU issue ceiling, wave-instr / clk / SIMD (profiles/r01_ubench_valu_lds.txt)
-ROUND = "r03"                 # which committed profiles/ files `traffic` and `valu_issue` are read from
+ROUND = "r04"                 # which committed profiles/ files `traffic` and `valu_issue` are read from
 ORBIT_STEP = 1.0e-3           # yaw per frame of the moving camera (rad)
 ORBIT_VIEWS = 64              # distinct views cycled through (consecutive frames never share one)
 

@@ -60,6 +60,8 @@ struct RtTraceFrame {                            // (rt_trace.hip)
     const uint32_t *sel;
     const uint32_t *sel_count;
     int lazy_geo;
+    const uint32_t *light_pair_count;
+    uint32_t light_pair_cap;
 };
 template <bool AA, bool STATS> __global__ void k_rt_trace2(const RtTraceFrame);
 __global__ void k_prep_select(const float *, int, const BinFrameDesc, const SelectOut);
@@ -217,6 +219,10 @@ struct Ctx {
     uint64_t frame_no = 0;                       // device calls so far
     int si = 0;                                  // index of the stream of the current / most recent call: calls take the streams in turn
     hipEvent_t ev_order[MAX_FLIGHT] = {};        // one per stream: orders work of one stream after what another has queued so far
+    // a side stream per stream: the light-cube pass of a frame whose camera AND lights moved runs there, beside the camera's pass
+    // (two latency-bound chains that share nothing until the trace kernel)
+    hipStream_t aux[MAX_FLIGHT] = {};
+    hipEvent_t ev_fork[MAX_FLIGHT] = {}, ev_join[MAX_FLIGHT] = {};
     // profiling events: one set per stream, so that the times of a frame survive the frames that follow it on the other streams
     // (mirt_get_previous_kernel_ms: the frame before the last one overlapped its neighbours on both sides)
     hipEvent_t ev_sets[MAX_FLIGHT][EV_COUNT] = {};
@@ -238,6 +244,9 @@ struct Ctx {
                                                  // (the event is re-recorded behind every such copy, and a stream runs in order: waiting
                                                  // for the latest record covers every earlier read of that stream)
     RtScratch rt[MAX_FLIGHT];                    // per-stream tables of the non-tile ray-trace paths (frames in flight)
+    RtScratch rt_lt[MAX_FLIGHT];                 // per stream: the pair lists, offsets and rows of a LIGHT-cube pass -- the cubes of lights
+                                                 // that move (binned by the frame) and the scratch of the shared cube's build -- apart from the
+                                                 // camera's, so that either pass is kept while only the other one's inputs change
     GeoRow *d_geo = nullptr;                     // n geometry rows (built by mirt_scene_upload)
     ShadeRow *d_shade = nullptr;                 // n shading rows (likewise)
     float bbox_lo[3] = { 0, 0, 0 }, bbox_hi[3] = { 0, 0, 0 };   // the scene's bounding box (host side, mirt_scene_upload)
@@ -371,6 +380,8 @@ hipError_t sync_all()
     hipError_t e = hipSuccess;
     for (int i = 0; i < MAX_FLIGHT; i++)
         if (g.streams[i]) { const hipError_t r = hipStreamSynchronize(g.streams[i]); if (r != hipSuccess) e = r; }
+    for (int i = 0; i < MAX_FLIGHT; i++)
+        if (g.aux[i]) { const hipError_t r = hipStreamSynchronize(g.aux[i]); if (r != hipSuccess) e = r; }
     if (g.comm_stream) { const hipError_t r = hipStreamSynchronize(g.comm_stream); if (r != hipSuccess) e = r; }
     return e;
 }
@@ -655,13 +666,17 @@ int light_shells_for(int nlights, int cube_bins, uint32_t keys_in_front)
     return ns;
 }
 
-// Room for the face lists of `nlights` light cubes (k_select_faces); the stream must be idle when they grow.
+constexpr size_t LIGHT_COUNTER_BYTES = sizeof(uint32_t) * (128 + 6 * MIRT_MAX_LIGHTS);
+// Room for the face lists of `nlights` light cubes (k_select_faces) in a stream's LIGHT scratch set; the stream must be idle when they grow.
 int ensure_face_lists(RtScratch &S, int nlights)
 {
     int rc;
-    if (!S.d_face_counts) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_face_counts), sizeof(uint32_t) * 6 * MIRT_MAX_LIGHTS));
-        HIP_TRY(hipMemsetAsync(S.d_face_counts, 0, sizeof(uint32_t) * 6 * MIRT_MAX_LIGHTS, g.stream));
+    if (!S.d_bin_counters) {
+        // the light pass's counters and the face lists' lengths in ONE block (a pass zeroes it with one fill): words 0..127 as in the
+        // camera's block, 128.. the face counts
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_bin_counters), LIGHT_COUNTER_BYTES));
+        HIP_TRY(hipMemsetAsync(S.d_bin_counters, 0, LIGHT_COUNTER_BYTES, g.stream));
+        S.d_face_counts = S.d_bin_counters + 128;
     }
     const size_t want = (size_t)6 * (size_t)nlights * (size_t)g.n;
     if (want > S.cap_face_sel) {
@@ -715,6 +730,7 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
         if ((rc = ensure_face_lists(S, nlights))) return rc;
         HIP_TRY(hipMemsetAsync(S.d_face_counts, 0, sizeof(uint32_t) * 6 * nlights, g.stream));
         HIP_TRY(hipMemsetAsync(C.d_counter, 0, 512, g.stream));
+        S.count_event_due = false;
         hipLaunchKernelGGL(k_select_faces, dim3((unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count), nlights), dim3(1024), 0, g.stream,
                            g.d_tris, g.n, C.d_origins, C.d_frames, C.d_light_tab, S.d_face_sel, (uint32_t)g.n, S.d_face_counts);
         BinSet bs;
@@ -820,7 +836,74 @@ int hist_publish(RtScratch &S)
     return MIRT_OK;
 }
 
-int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const float *origins, int nlights, int y0, int y1)
+// The cubes of lights that MOVE, binned by the frame itself (64 x 64 bins per face): a pass of its own in the stream's light
+// scratch set L -- the lights' origin rows and per-face selection lists (k_select_faces), pairs, sort, expanded rows --, apart from
+// the camera's pass, so that each is kept while only the other one's inputs change: a light key with the camera at rest
+// (raytracer.cpp:152-162, 385-537) re-bins the cubes and nothing else; the camera moving under lights that have not settled into the
+// shared cube yet re-bins the camera frame and nothing else.  *kept: the pass was not run.
+int transient_light_pass(RtScratch &L, const RtFrame &f, const float *origins, int nlights, int cube_bins, int tshells, uint32_t per_light, uint64_t lkey, bool *kept)
+{
+    int rc;
+    *kept = false;
+    uint64_t key = 0xcbf29ce484222325ull ^ g.scene_version;
+    {
+        auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
+        mix(&lkey, 8); mix(&cube_bins, 4); mix(&tshells, 4); mix(&g.n, 4); mix(&nlights, 4);
+    }
+    poll_pair_count(L);
+    bool fresh = !L.bin_key_valid || L.bin_key != key;
+    const bool may_guess = L.last_bin_mode == nlights;
+    if (!fresh && L.have_known && L.known_pairs > L.cap_used) fresh = true;   // (a kept list that turned out too small is rebuilt, so that it grows)
+    static const bool reuse_off = [] { const char *e = getenv("MIRT_BIN_REUSE"); return e && atoi(e) == 0; }();
+    if (!fresh && !reuse_off) { *kept = true; return MIRT_OK; }
+    if ((rc = ensure_face_lists(L, nlights))) return rc;
+    if (nlights > L.light_tab_lights || L.light_tab_n != g.n) {
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        L.light_tab_lights = 0;
+        if ((rc = dev_realloc(&L.d_light_tab, (size_t)nlights * g.n))) return rc;
+        L.light_tab_lights = nlights;
+        L.light_tab_n = g.n;
+    }
+    const uint32_t nkeys = per_light * (uint32_t)nlights;
+    if (nkeys + 1 > L.cap_bins) {
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        L.cap_bins = 0;
+        if ((rc = dev_realloc(&L.d_bin_off, (size_t)nkeys + 1))) return rc;
+        L.cap_bins = nkeys + 1;
+    }
+    // frame descriptors of the cubes and the origins in ONE buffer, one upload: [6 * nlights descriptors | (1 + nlights) x 3 floats]
+    if (!L.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&L.d_frames), sizeof(BinFrameDesc) * (6 * MIRT_MAX_LIGHTS) + sizeof(float) * 3 * (1 + MIRT_MAX_LIGHTS)));
+    struct { BinFrameDesc frames[6 * MIRT_MAX_LIGHTS]; float origins[3 * (1 + MIRT_MAX_LIGHTS)]; } up;
+    static_assert(sizeof(BinFrameDesc) % 4 == 0, "descriptors are uploaded as words");
+    fill_light_frames(up.frames, f, nlights, cube_bins, tshells, 0u);
+    float *d_origins = reinterpret_cast<float *>(L.d_frames + 6 * nlights);
+    memcpy(reinterpret_cast<char *>(up.frames + 6 * nlights), origins, sizeof(float) * 3 * (1 + nlights));      // (right behind the descriptors in use)
+    HIP_TRY(upload_small(L.d_frames, &up, sizeof(BinFrameDesc) * 6 * nlights + sizeof(float) * 3 * (1 + nlights), g.stream));
+    HIP_TRY(hipMemsetAsync(L.d_bin_counters, 0, LIGHT_COUNTER_BYTES, g.stream));     // the pass's pair counter and the face lists' lengths
+    hipLaunchKernelGGL(k_select_faces, dim3((unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count), nlights), dim3(1024), 0, g.stream,
+                       g.d_tris, g.n, d_origins, L.d_frames, L.d_light_tab, L.d_face_sel, (uint32_t)g.n, L.d_face_counts);
+    BinSet bs;
+    memset(&bs, 0, sizeof bs);
+    bs.frames = L.d_frames; bs.nframes = 6 * nlights; bs.nbins = nkeys; bs.bin_off = L.d_bin_off;
+    bs.face_lists = L.d_face_sel; bs.face_counts = L.d_face_counts; bs.face_stride = (uint32_t)g.n;
+    if ((rc = bin_pass(L, bs, nullptr, L.d_light_tab, L.d_bin_counters, L.d_bin_off, true, &L.bin_entries, may_guess))) return rc;
+    L.last_bin_mode = nlights;
+    L.bin_key = key;
+    L.bin_key_valid = true;
+    if (L.cap_light_rows < L.cap_entries) {                  // one row per pair at most; grown with the pair list (rare)
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        L.cap_light_rows = 0;
+        if ((rc = dev_realloc(&L.d_light_rows, (size_t)L.cap_entries))) return rc;
+        L.cap_light_rows = L.cap_entries;
+    }
+    const uint32_t expect = std::max<uint32_t>(L.bin_entries, 1u);
+    hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
+                       L.d_bin_off, L.d_entries, nlights, per_light, L.d_light_tab, g.n, L.d_light_rows, L.d_bin_counters, L.cap_used,
+                       g.d_tris, d_origins, (uint32_t *)nullptr);
+    return MIRT_OK;
+}
+
+int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, RtScratch &L, const float *origins, int nlights, int y0, int y1)
 {
     int rc;
     g.stats.mode_used = MIRT_RT_BINNED;
@@ -843,7 +926,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     const bool transient = nlights > 0 && !fixed_grid && !cached && g.lc.stable < LIGHT_STABLE_FRAMES;
 
     k_begin(MIRT_K_BIN);
-    if (!transient && (rc = light_cache_ensure(S, f, origins, nlights, fine_bins))) return rc;
+    if (!transient && (rc = light_cache_ensure(L, f, origins, nlights, fine_bins))) return rc;   // (in the light pass's scratch: the camera's tables stay)
     const int cube_bins = transient ? CUBE_BINS_MIN : fine_bins;
 
     BinSet bs;
@@ -870,11 +953,10 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         bs.frame0.shell_iw = okr ? (float)(ns / (df - dn)) : 0.0f;
     }
     const uint32_t cam_keys = (uint32_t)bs.frame0.nbu * (uint32_t)band_tile_rows * (uint32_t)bs.frame0.nshell;
-    // this frame's own light cubes (moving lights): their keys follow the camera's, from a multiple of their shell count on
-    const int tshells = transient ? light_shells_for(nlights, cube_bins, cam_keys) : 1;
-    const uint32_t light_key0 = transient ? (cam_keys + (uint32_t)tshells - 1u) / (uint32_t)tshells * (uint32_t)tshells : cam_keys;
+    // this frame's own light cubes (moving lights) are a pass of their own, with keys of their own (below)
+    const int tshells = transient ? light_shells_for(nlights, cube_bins, 0u) : 1;
     const uint32_t per_light = 6u * (uint32_t)(cube_bins * cube_bins) * (uint32_t)tshells;
-    bs.nbins = transient ? light_key0 + per_light * (uint32_t)nlights : cam_keys;
+    bs.nbins = cam_keys;
     if (bs.nbins + 1 > S.cap_bins) {
         const size_t cap = (size_t)bs.nbins + 1;
         HIP_TRY(hipStreamSynchronize(g.stream));             // (a frame of this stream may still read the old array)
@@ -900,9 +982,8 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     {
         auto mix = [&](const void *p, size_t nb) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < nb; i++) { key ^= b[i]; key *= 0x100000001b3ull; } };
         mix(view, sizeof *view); mix(&y0, 4); mix(&y1, 4); mix(&g.n, 4); mix(&g.aa, 4);
-        if (transient) { mix(&lkey, 8); mix(&cube_bins, 4); }
     }
-    const int bin_mode = transient ? 1 + nlights : 0;
+    const int bin_mode = 0;                                  // (the camera's pass bins the camera frame alone)
     g.hits_clean[g.hits_cur] = false;
     if (!S.d_frames) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.d_frames), sizeof(BinFrameDesc) * (1 + 6 * MIRT_MAX_LIGHTS)));
     // The pair count is read back (4 bytes + one sync of this stream) only when the inputs that determine it changed AND no
@@ -923,6 +1004,27 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     for (int j = bs.frame0.j0; j < bs.frame0.j1; j++) group_rows[((uint32_t)j >> ORDER_STRIPE_SHIFT) & (ORDER_GROUPS - 1)]++;
     const uint32_t order_seg = pairs_x * *std::max_element(group_rows, group_rows + ORDER_GROUPS);
     const uint32_t *cam_off = S.d_bin_off - (size_t)key_shift_tiles * (size_t)bs.frame0.nshell;   // indexed by the FRAME's tile number
+    // The cubes of lights that moved within the last frames: a pass of their own (transient_light_pass), kept while the lights stand
+    // still.  When the camera's pass runs as well, the light pass goes FIRST and onto the stream's side stream: the two chains
+    // share nothing until the trace kernel and are each bound by the latency of their launches, so side by side they take the longer
+    // one's time instead of the sum (one frame in flight, camera and light moving: 0.268 ms one after the other, see
+    // profiles/r04_moving_light.txt for the figure side by side).  The side stream starts behind everything the main stream has
+    // queued (the previous frame's trace kernel reads the tables the pass rewrites) and is joined in front of this frame's.
+    bool lights_kept = false, forked = false;
+    if (transient) {
+        static const bool side_off = [] { const char *e = getenv("MIRT_LIGHT_SIDE_STREAM"); return e && atoi(e) == 0; }();
+        hipStream_t main_stream = g.stream;
+        forked = !reuse && !side_off;
+        if (forked) {
+            HIP_TRY(hipEventRecord(g.ev_fork[g.si], main_stream));
+            HIP_TRY(hipStreamWaitEvent(g.aux[g.si], g.ev_fork[g.si], 0));
+            g.stream = g.aux[g.si];
+        }
+        rc = transient_light_pass(L, f, origins, nlights, cube_bins, tshells, per_light, lkey, &lights_kept);
+        g.stream = main_stream;
+        if (rc) return rc;
+        if (forked) HIP_TRY(hipEventRecord(g.ev_join[g.si], g.aux[g.si]));
+    }
     if (reuse) {
         // (the first kernel of a pass zeroes the frame's hit counters on the way; here nothing runs in front of the trace kernel)
         HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
@@ -936,10 +1038,6 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         so.cam_tab = S.d_cam_tab; so.sel = S.d_sel;
         so.sel_count = S.d_bin_counters + SEL_COUNT0 + S.sel_parity; so.sel_count_next = S.d_bin_counters + SEL_COUNT0 + (S.sel_parity ^ 1);
         so.zero_hits = g.d_hits; so.zero_counter = S.d_bin_counters;
-        if (transient) {
-            if ((rc = ensure_face_lists(S, nlights))) return rc;
-            so.zero_faces = S.d_face_counts; so.zero_faces_n = 6 * nlights;
-        }
         if ((rc = hist_prepare(S, bs.frame0, key, &so))) return rc;
         // one workgroup of 1024 threads per CU: a workgroup reserves its slice of the list with ONE atomic (rt_binned.hip)
         const unsigned sel_grid = (unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count);
@@ -947,43 +1045,10 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         if ((rc = hist_publish(S))) return rc;
         bs.sel = S.d_sel; bs.sel_count = so.sel_count;
         g.stats_sel_count = so.sel_count;
-        if (transient) {
-            // this stream's own light tables: origin rows per light, the cubes' frame descriptors behind the camera's, the rows
-            if (nlights > S.light_tab_lights || S.light_tab_n != g.n) {
-                HIP_TRY(hipStreamSynchronize(g.stream));
-                S.light_tab_lights = 0;
-                if ((rc = dev_realloc(&S.d_light_tab, (size_t)nlights * g.n))) return rc;
-                S.light_tab_lights = nlights;
-                S.light_tab_n = g.n;
-            }
-            BinFrameDesc frames[1 + 6 * MIRT_MAX_LIGHTS];
-            frames[0] = bs.frame0;
-            fill_light_frames(frames + 1, f, nlights, cube_bins, tshells, light_key0 / (uint32_t)tshells);
-            HIP_TRY(upload_small(S.d_frames, frames, sizeof(BinFrameDesc) * (1 + 6 * nlights), g.stream));
-            HIP_TRY(upload_small(S.d_origins, origins, sizeof(float) * 3 * (1 + nlights), g.stream));
-            bs.frames = S.d_frames; bs.nframes = 1 + 6 * nlights;
-            // origin rows of every light (all triangles: a shadow ray of a frame that falls back to brute force walks them all) and,
-            // per cube face, the list of the triangles it can see (k_prep_select above has zeroed the lists' counters)
-            hipLaunchKernelGGL(k_select_faces, dim3((unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count), nlights), dim3(1024), 0, g.stream,
-                               g.d_tris, g.n, S.d_origins, S.d_frames + 1, S.d_light_tab, S.d_face_sel, (uint32_t)g.n, S.d_face_counts);
-            bs.face_lists = S.d_face_sel; bs.face_counts = S.d_face_counts; bs.face_stride = (uint32_t)g.n;
-        }
-        if ((rc = bin_pass(S, bs, S.d_cam_tab, transient ? S.d_light_tab : nullptr, S.d_bin_counters, S.d_bin_off, true, &S.bin_entries, may_guess))) return rc;
+        if ((rc = bin_pass(S, bs, S.d_cam_tab, nullptr, S.d_bin_counters, S.d_bin_off, true, &S.bin_entries, may_guess))) return rc;
         S.last_bin_mode = bin_mode;
         S.bin_key = key;
         S.bin_key_valid = true;
-        if (transient) {
-            if (S.cap_light_rows < S.cap_entries) {              // one row per pair at most; grown with the pair list (rare)
-                HIP_TRY(hipStreamSynchronize(g.stream));
-                S.cap_light_rows = 0;
-                if ((rc = dev_realloc(&S.d_light_rows, (size_t)S.cap_entries))) return rc;
-                S.cap_light_rows = S.cap_entries;
-            }
-            const uint32_t expect = std::max<uint32_t>(S.bin_entries, 1u);
-            hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                               S.d_bin_off + light_key0, S.d_entries, nlights, per_light, S.d_light_tab, g.n, S.d_light_rows, S.d_bin_counters, S.cap_used,
-                               g.d_tris, S.d_origins, (uint32_t *)nullptr);
-        }
         // the order the trace kernel's waves take the tile pairs in: per XCD group (pairs of tile rows dealt round-robin), longest
         // lists first
         if ((size_t)order_seg > S.cap_order) {
@@ -995,6 +1060,8 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
         hipLaunchKernelGGL(k_tile_order, dim3((pairs_x + 63) / 64, (unsigned)(bs.frame0.j1 - bs.frame0.j0)), dim3(64), 0, g.stream, cam_off, bs.frame0.nshell,
                            bs.frame0.nbu, bs.frame0.j0, bs.frame0.j1, S.d_bin_counters, S.cap_used, S.d_order, order_seg);
     }
+    if (forked) HIP_TRY(hipStreamWaitEvent(g.stream, g.ev_join[g.si], 0));
+    (void)lights_kept;
     k_end(MIRT_K_BIN);
 
     RtTraceFrame tf;
@@ -1002,7 +1069,7 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.f = f;
     tf.f.cam_tab = S.d_cam_tab;
     // (a frame whose pair list overflowed walks the origin tables themselves: every triangle for every ray)
-    tf.f.light_tab = transient ? S.d_light_tab : g.lc.d_light_tab;
+    tf.f.light_tab = transient ? L.d_light_tab : g.lc.d_light_tab;
     tf.f.unsafe = nullptr;
     tf.cam_off = cam_off;
     tf.cam_entries = S.d_entries;
@@ -1013,16 +1080,19 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     tf.lazy_geo = lazy_env >= 0 ? (lazy_env != 0) : (g.n >= 400000);
     tf.geo = g.d_geo;
     tf.shade = g.d_shade;
-    tf.light_off = transient ? S.d_bin_off + light_key0 : g.lc.d_off;
-    tf.light_rows = transient ? S.d_light_rows : g.lc.d_rows;
-    tf.light_tri = transient ? S.d_entries : g.lc.d_row_tri;
-    tf.light_frames = transient ? S.d_frames + 1 : g.lc.d_frames;
+    tf.light_off = transient ? L.d_bin_off : g.lc.d_off;
+    tf.light_rows = transient ? L.d_light_rows : g.lc.d_rows;
+    tf.light_tri = transient ? L.d_entries : g.lc.d_row_tri;
+    tf.light_frames = transient ? L.d_frames : g.lc.d_frames;
     tf.tiles_x = bs.frame0.nbu;
     tf.cube_bins = cube_bins;
     tf.cam_shells = bs.frame0.nshell;
     tf.light_shells = transient ? tshells : g.lc.shells;
     tf.pair_count = S.d_bin_counters;
     tf.pair_cap = S.cap_used;
+    // (lights binned by the frame: their own pass's count; the shared cube's tables are complete by construction)
+    tf.light_pair_count = transient ? L.d_bin_counters : nullptr;
+    tf.light_pair_cap = L.cap_used;
     // one wave per pair of 8 x 8 tiles
     tf.order = S.d_order; tf.order_count = S.d_bin_counters + 16; tf.order_seg = order_seg;
     // (waves never synchronise with each other: one-wave workgroups are the finest scheduling unit; 84 / 87 / 89 us with 1 / 2 / 4)
@@ -1040,11 +1110,12 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, const flo
     }
     k_end(MIRT_K_TRACE);
     HIP_TRY(hipGetLastError());
-    if (S.count_event_due) {
-        S.count_event_due = false;
-        HIP_TRY(hipEventRecord(S.ev_count, g.stream));
-        S.count_pending = true;
-    }
+    for (RtScratch *P : { &S, &L })
+        if (P->count_event_due) {
+            P->count_event_due = false;
+            HIP_TRY(hipEventRecord(P->ev_count, g.stream));
+            P->count_pending = true;
+        }
     call_end();
     return MIRT_OK;
 }
@@ -1230,7 +1301,7 @@ int rt_enqueue(const mirt_view *view, const mirt_light *lights, int nlights, con
         return MIRT_OK;
     }
 
-    if (binned) return rt_enqueue_binned(f, view, S, origins, nlights, y0, y1);
+    if (binned) return rt_enqueue_binned(f, view, S, g.rt_lt[si], origins, nlights, y0, y1);
 
     HIP_TRY(upload_small(S.d_flags, flags_init, sizeof flags_init, g.stream));
     S.bin_key_valid = false;                     // (k_prep_origin below overwrites the camera rows a kept binning pass would count on)
@@ -1384,6 +1455,9 @@ extern "C" int mirt_init(int device)
         HIP_TRY(hipEventCreateWithFlags(&g.ev_order[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&g.ev_cull_read[i], hipEventDisableTiming));
         g.cull_read_src[i] = 0u;
+        HIP_TRY(hipStreamCreateWithFlags(&g.aux[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_fork[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_join[i], hipEventDisableTiming));
     }
     g.stream = g.streams[0];
     g.in_flight = 1;
@@ -1409,19 +1483,19 @@ extern "C" void mirt_shutdown(void)
     if (!g.init) return;
     (void)hipSetDevice(g.device);
     for (int i = 0; i < MAX_FLIGHT; i++) if (g.streams[i]) (void)hipStreamSynchronize(g.streams[i]);
-    for (RtScratch &S : g.rt)
-        for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_light_rows, (void *)S.d_order, (void *)S.d_bin_off,
-                         (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, (void *)S.d_tmp_vals, (void *)S.d_bucket })
-            if (p) (void)hipFree(p);
-    for (RtScratch &S : g.rt) { if (S.h_count) (void)hipHostFree(S.h_count); if (S.ev_count) (void)hipEventDestroy(S.ev_count); }
-    for (RtScratch &S : g.rt) {
-        if (S.d_sel) (void)hipFree(S.d_sel);
-        if (S.d_face_sel) (void)hipFree(S.d_face_sel);
-        if (S.d_face_counts) (void)hipFree(S.d_face_counts);
-        if (S.d_hist) (void)hipFree(S.d_hist);
-        if (S.h_hist) (void)hipHostFree(S.h_hist);
-        for (hipEvent_t e : S.ev_hist) if (e) (void)hipEventDestroy(e);
-    }
+    for (int i = 0; i < MAX_FLIGHT; i++) if (g.aux[i]) (void)hipStreamSynchronize(g.aux[i]);
+    for (RtScratch *set : { g.rt, g.rt_lt })
+        for (int i = 0; i < MAX_FLIGHT; i++) {
+            RtScratch &S = set[i];
+            for (void *p : { (void *)S.d_cam_tab, (void *)S.d_light_tab, (void *)S.d_origins, (void *)S.d_flags, (void *)S.d_frames, (void *)S.d_light_rows, (void *)S.d_order, (void *)S.d_bin_off,
+                             (void *)S.d_bin_counters, (void *)S.d_entries, (void *)S.d_pair_keys, (void *)S.d_pair_vals, (void *)S.d_sorted_keys, (void *)S.d_tmp_vals, (void *)S.d_bucket,
+                             (void *)S.d_sel, (void *)S.d_face_sel, (void *)S.d_hist })     // (d_face_counts lies inside d_bin_counters' block)
+                if (p) (void)hipFree(p);
+            if (S.h_count) (void)hipHostFree(S.h_count);
+            if (S.ev_count) (void)hipEventDestroy(S.ev_count);
+            if (S.h_hist) (void)hipHostFree(S.h_hist);
+            for (hipEvent_t e : S.ev_hist) if (e) (void)hipEventDestroy(e);
+        }
     for (void *p : { (void *)g.d_geo, (void *)g.d_shade, (void *)g.lc.d_light_tab, (void *)g.lc.d_frames, (void *)g.lc.d_off, (void *)g.lc.d_rows, (void *)g.lc.d_row_tri, (void *)g.lc.d_origins, (void *)g.lc.d_counter })
         if (p) (void)hipFree(p);
     for (void *p : { (void *)g.d_tris, (void *)g.d_culled, g.d_xrgb, g.d_rgb, g.d_index, g.d_zinv, g.d_pos })
@@ -1441,6 +1515,9 @@ extern "C" void mirt_shutdown(void)
     for (int si = 0; si < MAX_FLIGHT; si++) for (int i = 0; i < EV_COUNT; i++) if (g.ev_sets[si][i]) { (void)hipEventDestroy(g.ev_sets[si][i]); g.ev_sets[si][i] = nullptr; }
     for (hipEvent_t e : g.ev_order) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : g.ev_cull_read) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_fork) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g.ev_join) if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < MAX_FLIGHT; i++) if (g.aux[i]) (void)hipStreamDestroy(g.aux[i]);
     for (int i = 0; i < MAX_FLIGHT; i++) if (g.streams[i]) (void)hipStreamDestroy(g.streams[i]);
     g = Ctx();
 }
@@ -1545,6 +1622,7 @@ extern "C" int mirt_scene_upload(const float *tris15, const uint8_t *culled, int
     if ((rc = dev_realloc(&g.d_tris, (size_t)n * 15))) return rc;
     if ((rc = dev_realloc(&g.d_culled, (size_t)MAX_FLIGHT * n))) return rc;
     for (RtScratch &S : g.rt) { S.bin_key_valid = false; S.have_known = false; S.count_pending = false; }   // tables and pair counts belong to the old scene
+    for (RtScratch &S : g.rt_lt) { S.bin_key_valid = false; S.have_known = false; S.count_pending = false; }
     for (RtScratch &S : g.rt) for (uint64_t &k : S.hist_key) k = 0;                                          // ... and so do the cost histograms
     HIP_TRY(hipMemcpy(g.d_tris, tris15, (size_t)n * 15 * sizeof(float), hipMemcpyHostToDevice));
     g.cull_calls++;

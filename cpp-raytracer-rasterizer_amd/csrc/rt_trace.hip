@@ -259,6 +259,8 @@ struct RtTraceFrame {
     const uint32_t *sel_count;        // back to brute force walks (their origin rows are the ones the frame has built)
     int lazy_geo;                     // 1: geometry rows are fetched by the exact stage, for the pairs it accepts, instead of being staged
                                       // with every candidate (scenes whose tables no longer fit the caches: see the staging code)
+    const uint32_t *light_pair_count; // the same for the light-cube lists when a pass of their own built them (nullable: the shared,
+    uint32_t light_pair_cap;          // cached cube never overflows): beyond it the shadow rays walk the lights' origin tables
 };
 
 // One wave renders one PAIR of horizontally adjacent tiles.  Two things decide which wave takes which pair:
@@ -366,6 +368,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
 #endif
     // the pair list overflowed (it was sized from an earlier frame's count): no lists -- every tile takes every triangle
     const bool brute = (uint32_t)__builtin_amdgcn_readfirstlane((int)*tf.pair_count) > tf.pair_cap;
+    // ... and the light lists: their own pass's count where there was one
+    const bool brute_l = tf.light_pair_count ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*tf.light_pair_count) > tf.light_pair_cap : false;
     const v3 cam = ld3(f.cam);
     const int rs = AA ? f.aa : 1;                          // realSamples (:549-554); compile-time 1 without supersampling
 
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     // later shell has near > 0.99 r (bin_shell_of is monotone in its argument) and cannot occlude (:313)
                     uint32_t eA = 0, endA = 0, eB = 0, endB = 0;
                     const float4 *rows4;
-                    if (brute) {
+                    if (brute_l) {
                         rows4 = reinterpret_cast<const float4 *>(f.light_tab + (size_t)k * f.n);
                         if (hitA) endA = (uint32_t)f.n;
                         if (hitB) endB = (uint32_t)f.n;
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     // tests nested in ifs, the compiler kept each boolean as a scalar lane mask and merged it with exec at every
                     // divergent join: ~60 scalar instructions per step beside ~30 vector ones -- and at the four waves per SIMD this
                     // kernel runs at, a scalar instruction costs what a vector one costs (profiles/r03_issue_model.txt).
-                    const uint32_t *row_tri = brute ? nullptr : tf.light_tri;
+                    const uint32_t *row_tri = brute_l ? nullptr : tf.light_tri;
                     const bool firstA = eA < endA;
                     uint32_t e = firstA ? eA : eB, end = firstA ? endA : endB, pix = firstA ? (uint32_t)lane : (uint32_t)lane + 64u;
                     v3 crd = firstA ? half0(rd) : half1(rd);
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     float4 c0, c1, c2;
                     { const float4 *src = rows4 + (size_t)(e < end ? e : 0u) * 3; c0 = src[0]; c1 = src[1]; c2 = src[2]; }
                     TM_SEG(6)
-                    const int not_brute = brute ? 0 : 1;
+                    const int not_brute = brute_l ? 0 : 1;
                     for (;;) {
                         const bool act = e < end;
                         const unsigned long long am = wballot(act);

@@ -86,9 +86,9 @@ typedef struct mirt_stats {
     uint64_t steps_primary;
     uint64_t steps_shadow;
     uint64_t drains;
-    /* binned ray tracer (ABI 4): 1 when the frame started at the trace kernel -- nothing its binning pass depends on had changed
-     * since the stream's last pass (the view stood still: a light key, a toggle; raytracer.cpp:385-537) --, and how many of the
-     * scene's triangles the rows of the call can see at all (what its binning pass walked; 0 when no pass ran) */
+    /* binned ray tracer (ABI 4): 1 when the frame kept the CAMERA's binning pass of its stream -- nothing that pass depends on had
+     * changed since (the view stood still: a light key, a toggle; raytracer.cpp:385-537) --, and how many of the scene's triangles
+     * the rows of the call can see at all (what the camera's pass walked; 0 when it was kept) */
     uint32_t bins_reused;
     uint32_t selected_triangles;
 } mirt_stats;
