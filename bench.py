@@ -126,20 +126,31 @@ def measured_traffic(workload, kernel_prefixes, per_frame=False):
     those the pass saw more than twice (the per-scene table builders, the one-off light-cube build and torch's fills run once or
     twice), each weighted by its launches per frame."""
     w = committed_profile("%s_hbm_traffic.json" % ROUND, workload)
-    ks = {k: v for k, v in w.items() if any(k.replace("mirt::", "").replace("void ", "").startswith(p) for p in kernel_prefixes)}
+    ks = one_instantiation({k: v for k, v in w.items() if any(k.replace("mirt::", "").replace("void ", "").startswith(p) for p in kernel_prefixes)})
     if per_frame:
         ks = {k: v for k, v in ks.items() if v.get("launches", 0) > 2}
         most = max((v["launches"] for v in ks.values()), default=0)
-        tot = sum((v["fetch_bytes"] + v["write_bytes"]) * v["launches"] / most for v in ks.values()) if most else 0
+        tot = sum((v["fetch_bytes"] + v["write_bytes"]) * min(1.0, v["launches"] / most) for v in ks.values()) if most else 0
     else:
         tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in ks.values())
     return int(tot) or None
 
 
+def one_instantiation(kernels):
+    """Of the instantiations of one kernel template a pass saw (k_rt_trace2<false, false> in the frames of the loop, <false, true> --
+    the one that keeps statistics -- in the profiled frames) only the one launched most: they are the same launch counted twice."""
+    best = {}
+    for k, v in kernels.items():
+        base = k.split("<")[0]
+        if base not in best or v.get("launches", 0) > best[base][1].get("launches", 0):
+            best[base] = (k, v)
+    return {k: v for k, v in best.values()}
+
+
 def measured_valu_instructions(workload, kernel_prefix):
     """Wave-level VALU instructions per launch of the named kernel from the committed rocprofv3 PMC pass
     (profiles/<round>_pmc_issue.json: SQ_INSTS_VALU averaged over the launches), or None."""
-    for k, v in committed_profile("%s_pmc_issue.json" % ROUND, workload).items():
+    for k, v in one_instantiation(committed_profile("%s_pmc_issue.json" % ROUND, workload)).items():
         if kernel_prefix in k and "SQ_INSTS_VALU" in v:
             return float(v["SQ_INSTS_VALU"])
     return None
@@ -147,7 +158,7 @@ def measured_valu_instructions(workload, kernel_prefix):
 
 def measured_counter(workload, kernel_prefix, counter):
     """Any counter of the named kernel from the same committed pass (per launch), or None."""
-    for k, v in committed_profile("%s_pmc_issue.json" % ROUND, workload).items():
+    for k, v in one_instantiation(committed_profile("%s_pmc_issue.json" % ROUND, workload)).items():
         if kernel_prefix in k and counter in v:
             return float(v[counter])
     return None
@@ -169,12 +180,12 @@ def all_kinds_issue(workload, kernel_prefix, kernel_ms):
 def measured_valu_per_frame(workload):
     """VALU instructions of ALL per-frame kernels of the workload (every kernel the PMC pass saw more than twice: the
     per-scene table builders run once), per frame, from the same committed pass; or None."""
-    ks = committed_profile("%s_pmc_issue.json" % ROUND, workload)
+    ks = one_instantiation(committed_profile("%s_pmc_issue.json" % ROUND, workload))
     per_frame = [v for v in ks.values() if "SQ_INSTS_VALU" in v and v.get("launches", 0) > 2]
     if not per_frame:
         return None
     most = max(v["launches"] for v in per_frame)
-    return sum(float(v["SQ_INSTS_VALU"]) * v["launches"] / most for v in per_frame)
+    return sum(float(v["SQ_INSTS_VALU"]) * min(1.0, v["launches"] / most) for v in per_frame)
 
 
 def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, samples=1, jitter=None, aa=1):
@@ -342,6 +353,8 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     # frames are dispatched -- and fill the device's gaps -- while the previous ones drain).  Several GPUs: one frame in
     # flight per rank, the RCCL gather of the previous batch overlaps it instead.
     in_flight = int(os.environ.get("MIRT_BENCH_IN_FLIGHT", "4")) if world == 1 else 1
+    if quick:
+        in_flight = 1                                   # (frames of a sixth of a second each fill the chip alone)
     depth = max(2, in_flight)
     # Several GPUs: frames that render faster than a collective starts (the 30-triangle scenes) travel `batch` at a time --
     # one RCCL gather moves the bands of 32 consecutive frames; heavy frames (the soups: milliseconds) go one per gather.
@@ -445,7 +458,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     probe_frames = 2 if quick else max(2 * batch, 8)
     t_frame = timed(probe_frames) / probe_frames
     t_frame = env.reduce([t_frame], dist.ReduceOp.MAX)[0] if world > 1 else t_frame
-    fps_step = max(1, int(np.ceil(target_s / (steps * max(t_frame, 1e-7)))))
+    fps_step = max(1, int(np.ceil(1.3 * target_s / (steps * max(t_frame, 1e-7)))))       # (a third over: the probe's frames run a little slower than the loop's)
     if world > 1:
         fps_step = ((fps_step + batch - 1) // batch) * batch
     for _ in range(warmup):
