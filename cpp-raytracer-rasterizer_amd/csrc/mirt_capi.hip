@@ -107,8 +107,28 @@ __global__ __launch_bounds__(256) void k_upload_words(const UploadChunk c, uint3
 {
     for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = c.w[i];
 }
-hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t stream)
+// ... and, in the same launch, up to two regions to zero (a pass's counters, the frame's hit counters): a fill of its own is a launch
+// of its own, ~3 us of a single frame's latency each.
+struct ZeroJob { uint32_t *a; int na; uint32_t *b; int nb; };
+__global__ __launch_bounds__(256) void k_upload_words_zero(const UploadChunk c, uint32_t *__restrict__ dst, int nwords, const ZeroJob z)
 {
+    for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = c.w[i];
+    for (int i = threadIdx.x; i < z.na; i += 256) z.a[i] = 0u;
+    for (int i = threadIdx.x; i < z.nb; i += 256) z.b[i] = 0u;
+}
+hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t stream, const ZeroJob *zero = nullptr);
+hipError_t upload_small(void *dst, const void *src, size_t bytes, hipStream_t stream, const ZeroJob *zero)
+{
+    if (zero) {
+        // (the zero job rides on the first chunk)
+        const uint32_t *w0 = static_cast<const uint32_t *>(src);
+        UploadChunk c0;
+        const int n0 = (int)std::min<size_t>(768, bytes / 4);
+        memcpy(c0.w, w0, (size_t)n0 * 4);
+        hipLaunchKernelGGL(k_upload_words_zero, dim3(1), dim3(256), 0, stream, c0, static_cast<uint32_t *>(dst), n0, *zero);
+        if (bytes / 4 <= 768) return hipGetLastError();
+        return upload_small(static_cast<uint32_t *>(dst) + 768, w0 + 768, bytes - 768 * 4, stream, nullptr);
+    }
     const uint32_t *w = static_cast<const uint32_t *>(src);
     uint32_t *d = static_cast<uint32_t *>(dst);
     for (size_t off = 0, nw = bytes / 4; off < nw; off += 768) {
@@ -841,7 +861,8 @@ int hist_publish(RtScratch &S)
 // the camera's pass, so that each is kept while only the other one's inputs change: a light key with the camera at rest
 // (raytracer.cpp:152-162, 385-537) re-bins the cubes and nothing else; the camera moving under lights that have not settled into the
 // shared cube yet re-bins the camera frame and nothing else.  *kept: the pass was not run.
-int transient_light_pass(RtScratch &L, const RtFrame &f, const float *origins, int nlights, int cube_bins, int tshells, uint32_t per_light, uint64_t lkey, bool *kept)
+int transient_light_pass(RtScratch &L, const RtFrame &f, const float *origins, int nlights, int cube_bins, int tshells, uint32_t per_light, uint64_t lkey, bool *kept,
+                         unsigned long long *zero_hits /* nullable: the frame's hit counters, zeroed by the pass's first launch when it runs */)
 {
     int rc;
     *kept = false;
@@ -878,8 +899,9 @@ int transient_light_pass(RtScratch &L, const RtFrame &f, const float *origins, i
     fill_light_frames(up.frames, f, nlights, cube_bins, tshells, 0u);
     float *d_origins = reinterpret_cast<float *>(L.d_frames + 6 * nlights);
     memcpy(reinterpret_cast<char *>(up.frames + 6 * nlights), origins, sizeof(float) * 3 * (1 + nlights));      // (right behind the descriptors in use)
-    HIP_TRY(upload_small(L.d_frames, &up, sizeof(BinFrameDesc) * 6 * nlights + sizeof(float) * 3 * (1 + nlights), g.stream));
-    HIP_TRY(hipMemsetAsync(L.d_bin_counters, 0, LIGHT_COUNTER_BYTES, g.stream));     // the pass's pair counter and the face lists' lengths
+    // (the same launch zeroes the pass's pair counter and the face lists' lengths)
+    const ZeroJob zj = { L.d_bin_counters, (int)(LIGHT_COUNTER_BYTES / 4), reinterpret_cast<uint32_t *>(zero_hits), zero_hits ? 2 * HIT_SHARDS * HIT_SHARD_STRIDE : 0 };
+    HIP_TRY(upload_small(L.d_frames, &up, sizeof(BinFrameDesc) * 6 * nlights + sizeof(float) * 3 * (1 + nlights), g.stream, &zj));
     hipLaunchKernelGGL(k_select_faces, dim3((unsigned)std::min<long long>(((long long)g.n + 1023) / 1024, (long long)g.cu_count), nlights), dim3(1024), 0, g.stream,
                        g.d_tris, g.n, d_origins, L.d_frames, L.d_light_tab, L.d_face_sel, (uint32_t)g.n, L.d_face_counts);
     BinSet bs;
@@ -1020,14 +1042,16 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, RtScratch
             HIP_TRY(hipStreamWaitEvent(g.aux[g.si], g.ev_fork[g.si], 0));
             g.stream = g.aux[g.si];
         }
-        rc = transient_light_pass(L, f, origins, nlights, cube_bins, tshells, per_light, lkey, &lights_kept);
+        // (with the camera's pass kept nothing else runs in front of the trace kernel: the light pass's first launch zeroes the hit counters too)
+        rc = transient_light_pass(L, f, origins, nlights, cube_bins, tshells, per_light, lkey, &lights_kept, reuse ? g.d_hits : nullptr);
         g.stream = main_stream;
         if (rc) return rc;
         if (forked) HIP_TRY(hipEventRecord(g.ev_join[g.si], g.aux[g.si]));
     }
     if (reuse) {
-        // (the first kernel of a pass zeroes the frame's hit counters on the way; here nothing runs in front of the trace kernel)
-        HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
+        // (the first kernel of a pass zeroes the frame's hit counters on the way; here nothing runs in front of the trace kernel --
+        // unless the light pass has just run and done it)
+        if (!(transient && !lights_kept)) HIP_TRY(hipMemsetAsync(g.d_hits, 0, sizeof(unsigned long long) * HIT_SHARDS * HIT_SHARD_STRIDE, g.stream));
         g.stats.bins_reused = 1;
     } else {
         // first kernel of the frame: the camera's origin rows for the triangles the rows of this call can see, and their list

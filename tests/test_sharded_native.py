@@ -325,7 +325,8 @@ print("selfcheck ok", flush=True)
 
 
 @pytest.mark.gpu
-def test_sharded_frames_over_rccl_on_two_devices(tmp_path):
+@pytest.mark.parametrize("strip", [0, -1])
+def test_sharded_frames_over_rccl_on_two_devices(tmp_path, strip):
     """The same frames with one rank per DEVICE and the library's RCCL transport (grouped ncclSend / ncclRecv over xGMI): the
     multi-GPU path as bench.py --gpus N runs it.  Needs two GPUs; skipped on a one-GPU box (where the loopback transport and the
     group of one rank above are what can run)."""
@@ -335,6 +336,7 @@ def test_sharded_frames_over_rccl_on_two_devices(tmp_path):
     code = RANK_CODE % {"pkg": os.path.join(ROOT, "cpp-raytracer-rasterizer_amd"), "tests": os.path.join(ROOT, "tests")}
     env = {k: v for k, v in os.environ.items() if k != "MIRT_COMM"}
     env["MIRT_TEST_DEVICE_PER_RANK"] = "1"
+    env["MIRT_TEST_STRIP_ROWS"] = str(strip)               # 0: equal bands, -1: the cost-weighted partition
     idfile = str(tmp_path / "comm_id")
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", "0", idfile], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
