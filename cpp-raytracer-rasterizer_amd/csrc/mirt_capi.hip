@@ -68,8 +68,7 @@ __global__ void k_prep_select(const float *, int, const BinFrameDesc, const Sele
 __global__ void k_select_faces(const float *, int, const float *, const BinFrameDesc *, OriginRow *, uint32_t *, uint32_t, uint32_t *);
 __global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *, uint32_t);
 __global__ void k_geo_table(const float *, int, GeoRow *, ShadeRow *);
-__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t,
-                                    const float *, const float *, uint32_t *);
+__global__ void k_expand_light_rows(const uint32_t *, const uint32_t *, int, uint32_t, const OriginRow *, int, LightRow *, const uint32_t *, uint32_t, uint32_t *);
 size_t rt_trace_lds_bytes(int waves);
 int launch_raster(RasterFrame &f, RasterScratch &s, uint64_t scene_version, hipStream_t stream, hipEvent_t *ev, bool *ev_used);
 __global__ void k_cull(const float *, int, const CullParams, uint8_t *);
@@ -769,8 +768,7 @@ int light_cache_ensure(RtScratch &S, const RtFrame &f, const float *origins, int
         C.nrows = npairs;
         if (npairs)
             hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((npairs + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.n, C.d_rows, (const uint32_t *)nullptr, 0u,
-                               g.d_tris, C.d_origins, C.d_row_tri);
+                               C.d_off, S.d_entries, nlights, per_light, C.d_light_tab, g.n, C.d_rows, (const uint32_t *)nullptr, 0u, C.d_row_tri);
         HIP_TRY(hipGetLastError());
         S.bin_key_valid = false;                             // the stream's pair list now holds the light pass
         S.last_bin_mode = -1;
@@ -920,8 +918,7 @@ int transient_light_pass(RtScratch &L, const RtFrame &f, const float *origins, i
     }
     const uint32_t expect = std::max<uint32_t>(L.bin_entries, 1u);
     hipLaunchKernelGGL(k_expand_light_rows, dim3((unsigned)std::min<uint32_t>((expect + 255) / 256, 4096u)), dim3(256), 0, g.stream,
-                       L.d_bin_off, L.d_entries, nlights, per_light, L.d_light_tab, g.n, L.d_light_rows, L.d_bin_counters, L.cap_used,
-                       g.d_tris, d_origins, (uint32_t *)nullptr);
+                       L.d_bin_off, L.d_entries, nlights, per_light, L.d_light_tab, g.n, L.d_light_rows, L.d_bin_counters, L.cap_used, (uint32_t *)nullptr);
     return MIRT_OK;
 }
 

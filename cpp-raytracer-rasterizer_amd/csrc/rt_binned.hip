@@ -321,9 +321,10 @@ __global__ __launch_bounds__(SEL_WG) void k_select_faces(const float *__restrict
         uint32_t keep = 0;
         if (i < n) {
             const float *t15 = tris15 + (size_t)15 * i;
-            const OriginRow r = make_origin_row(t15, S);
-            light_tab[(size_t)k * n + i] = r;
+            OriginRow r = make_origin_row(t15, S);
             const v3 va = ld3(t15), vb = ld3(t15 + 3), vc = ld3(t15 + 6);
+            r.r2.w = origin_far(va, vb, vc, S);           // the spare word: no point of the triangle is farther from this light (k_expand_light_rows copies it)
+            light_tab[(size_t)k * n + i] = r;
             for (int f = 0; f < 6; f++) {
                 PreBox box;
                 bool boxed;

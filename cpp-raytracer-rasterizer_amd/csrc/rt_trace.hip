@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_geo_table(const float *__restrict__ tri
 }
 
 // rows[p] = origin row of triangle entries[p] for the light its key belongs to, with the `far` bound of that triangle from that
-// light in r2.w (origin_far: no point of it is farther), and row_tri[p] = the triangle (for the few pairs that reach the exact
+// light in r2.w (origin_far: no point of it is farther; k_select_faces computes it where the vertices are at hand -- this kernel
+// used to fetch them again per row, uncoalesced), and row_tri[p] = the triangle (for the few pairs that reach the exact
 // stage): the sorted pair list of the light-cube frames, expanded so that a shadow ray reads its candidates sequentially.  bin_off points at the
 // first light key (the pairs of keys in front of it -- a camera frame binned in the same pass -- are not light pairs);
 // bin_off[k * keys_per_light] is where the pairs of light k start (keys_per_light = 6 * B * B * depth shells).  pair_count /
@@ -68,7 +69,6 @@ __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__res
                                                            int nlights, uint32_t keys_per_light,
                                                            const OriginRow *__restrict__ light_tab, int n,
                                                            LightRow *__restrict__ rows, const uint32_t *__restrict__ pair_count, uint32_t pair_cap,
-                                                           const float *__restrict__ tris15, const float *__restrict__ origins /* (1 + nlights) x 3 */,
                                                            uint32_t *__restrict__ row_tri /* nullable: entries itself serves */)
 {
     if (pair_count && *pair_count > pair_cap) return;
@@ -77,10 +77,7 @@ __global__ __launch_bounds__(256) void k_expand_light_rows(const uint32_t *__res
         int k = 0;
         while (k + 1 < nlights && bin_off[(size_t)(k + 1) * keys_per_light] <= p) k++;
         const uint32_t tri = entries[p];
-        LightRow r = light_tab[(size_t)k * n + tri];
-        const float *t15 = tris15 + (size_t)15 * tri;
-        r.r2.w = origin_far(ld3(t15), ld3(t15 + 3), ld3(t15 + 6), ld3(origins + 3 * (1 + k)));
-        rows[p] = r;
+        rows[p] = light_tab[(size_t)k * n + tri];          // (r2.w = the `far` bound: k_select_faces put it there, per (triangle, light))
         if (row_tri) row_tri[p] = tri;
     }
 }
@@ -194,8 +191,7 @@ __device__ __forceinline__ int wave_rank(unsigned long long m)      // lanes bel
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// cube_bin_of (rt_binned.hpp) for the two shadow rays of a lane: the same selections and the same operations per half, the
-// four divisions as two packed pairs (div2 rounds each half like `/`).
+// cube_bin_of (rt_binned.hpp) for the two shadow rays of a lane: the same selections per half.
 __device__ __forceinline__ void cube_bin_of2(const v3p &rd, uint32_t face_base0, int cube_bins, uint32_t *bin0, uint32_t *bin1)
 {
     f2 a, b, m;
@@ -212,8 +208,13 @@ __device__ __forceinline__ void cube_bin_of2(const v3p &rd, uint32_t face_base0,
         face[h] = 2 * k + (sgn < 0.0f ? 1 : 0);
         if (h) { a.y = aa; b.y = bb; m.y = mm; } else { a.x = aa; b.x = bb; m.x = mm; }
     }
-    // u, v in [-1,1]; NaN (degenerate ray, never accepted by any triangle) falls into bin 0
-    const f2 u = div2(a, m), v = div2(b, m);
+    // u, v in [-1,1]; NaN (degenerate ray, never accepted by any triangle) falls into bin 0.  The quotients only CHOOSE the bin: one
+    // reciprocal per ray (1 ulp) and two products put u, v within 2^-22 of the exact ones, and a bin's list holds every triangle a
+    // ray within 2^-18 of its rectangle can hit (the cubes' pad, fill_light_frames) -- so the bin a ray lands in, this one or its
+    // neighbour across an edge it grazes, has the ray's candidates either way.  (Four IEEE divisions here were 4 % of the kernel's
+    // vector instructions.)
+    const f2 im = { __builtin_amdgcn_rcpf(m.x), __builtin_amdgcn_rcpf(m.y) };
+    const f2 u = a * im, v = b * im;
     const float half = 0.5f * (float)cube_bins;
     const uint32_t per_face = (uint32_t)(cube_bins * cube_bins);
 #pragma unroll
