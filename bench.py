@@ -164,6 +164,18 @@ def measured_counter(workload, kernel_prefix, counter):
     return None
 
 
+def valu_plus_salu_issue(workload, kernel_prefix, kernel_ms):
+    """Vector AND scalar instructions per launch (SQ_INSTS_VALU + SQ_INSTS_SALU) over the kernel's duration, per SIMD and clock, against
+    the measured issue ceiling of a vector stream: at the four or five waves per SIMD these kernels run at a scalar instruction is not
+    free (profiles/r03_issue_model.txt), so the two together are what the issue side is offered."""
+    nv, ns = measured_counter(workload, kernel_prefix, "SQ_INSTS_VALU"), measured_counter(workload, kernel_prefix, "SQ_INSTS_SALU")
+    if not nv or ns is None or kernel_ms <= 0:
+        return None
+    ipc = (nv + ns) / (kernel_ms * 1e-3 * 2.4e9 * 1024)
+    return {"valu_per_launch": int(nv), "salu_per_launch": int(ns), "achieved": round(ipc, 4), "peak": ISSUE_CEILING, "frac": round(ipc / ISSUE_CEILING, 4),
+            "unit": "vector + scalar wave-instr/clk/SIMD", "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU + SQ_INSTS_SALU)" % ROUND}
+
+
 def all_kinds_issue(workload, kernel_prefix, kernel_ms):
     """Issue-active slots of ANY instruction kind (SQ_ACTIVE_INST_ANY: vector, scalar, LDS, memory, branch, wait; equals the
     instruction count for vector instructions, counts an LDS / memory instruction that holds its pipe longer more than once) per
@@ -651,6 +663,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                 # every instruction kind over the launch ALONE on the device: the stream as a whole against the issue rate
                 if kernel_ms_alone and kernel_ms_alone.get("trace", 0.0) > 0:
                     out["roofline"]["valu_issue"]["all_kinds_alone"] = all_kinds_issue(name, kname, kernel_ms_alone["trace"])
+                    out["roofline"]["valu_issue"]["valu_plus_salu_alone"] = valu_plus_salu_issue(name, kname, kernel_ms_alone["trace"])
                 # ... and of the whole frame: launches of consecutive frames overlap (frames in flight), so what the chip's vector
                 # pipes did per frame is every per-frame kernel's instructions over the FRAME time -- the roofline of the loop
                 per_frame = measured_valu_per_frame(name)
@@ -712,6 +725,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                                                      "source": "profiles/%s_pmc_issue.json (SQ_INSTS_VALU)" % ROUND}
                     if kernel_ms_alone and kernel_ms_alone.get("raster_resolve", 0.0) > 0:
                         out["roofline"]["valu_issue"]["all_kinds_alone"] = all_kinds_issue(name, "k_raster_small", kernel_ms_alone["raster_resolve"])
+                        out["roofline"]["valu_issue"]["valu_plus_salu_alone"] = valu_plus_salu_issue(name, "k_raster_small", kernel_ms_alone["raster_resolve"])
                     per_frame = measured_valu_per_frame(name)
                     if per_frame:
                         fipc = per_frame / (ms_frame * 1e-3 * 2.4e9 * 1024)

@@ -8,9 +8,9 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_trace.json" 2> "$out/trace.err"
 echo "trace rc=$?"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$out/pmc1" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_pmc1.json" 2> "$out/pmc1.err"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$out/pmc1" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_pmc1.json" 2> "$out/pmc1.err"
 echo "pmc1 rc=$?"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_IFETCH SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc2" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_pmc2.json" 2> "$out/pmc2.err"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_IFETCH SQ_INST_CYCLES_VMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc2" -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_pmc2.json" 2> "$out/pmc2.err"
 echo "pmc2 rc=$?"
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
