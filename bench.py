@@ -473,8 +473,16 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
     fps_step = max(1, int(np.ceil(1.3 * target_s / (steps * max(t_frame, 1e-7)))))       # (a third over: the probe's frames run a little slower than the loop's)
     if world > 1:
         fps_step = ((fps_step + batch - 1) // batch) * batch
-    for _ in range(warmup):
-        timed(fps_step)
+    for w in range(warmup):
+        dw = timed(fps_step)
+        if w == 0 and target_s > 0:
+            # the probe's few frames overestimate what a long loop sustains for the fastest frames (the Cornell box at 500 x 500 takes 5 us):
+            # the first warm-up step says what a step really takes, and the steps grow until the timed region will last target_s
+            dw = env.reduce([dw], dist.ReduceOp.MIN)[0] if world > 1 else dw
+            if dw * steps < target_s:
+                fps_step = int(np.ceil(fps_step * 1.2 * target_s / max(dw * steps, 1e-9)))
+                if world > 1:
+                    fps_step = ((fps_step + batch - 1) // batch) * batch
     dt = timed(steps * fps_step)
     st = mirt.stats()
     dt = env.reduce([dt], dist.ReduceOp.MAX)[0] if world > 1 else dt
