@@ -15,11 +15,15 @@
 // the data: k_dof_tile stages a (32+K-1) x (64+K-1) tile of pixelColours in LDS; a thread owns eight
 // vertically adjacent outputs and walks the tile rows once, feeding each value it reads to every output whose window
 // holds that row -- each output still sees its taps in the reference's (z, z2) order.  HBM traffic is the
-// algorithmic 16 B read + 4 B written per pixel (plus the tile halo): 200 MB per 4K frame, ~40 us on this chip; the K*K*6 VALU
-// operations per pixel (no FMA: the reference multiplies, then adds) are 1472 packed instructions per thread of 1875, 52 us at
-// the issue ceiling.  74 us measured: the vector pipes are busy 73 % of it, whatever the structure -- 4 or 8 outputs per thread
-// (4 to 6 waves per SIMD), 24 or 8 LDS reads per tap row, or every wave streaming its own rows through an LDS ring with no
-// barrier at all (a variant built, measured at 73.5 us and removed).
+// algorithmic 16 B read + 4 B written per pixel: 136 MB fetched per 4K frame by the counters once the tiles of an XCD are
+// neighbours (303 MB with tiles dealt row-major over the XCDs: every tile's halo came over the fabric); the K*K*6 VALU
+// operations per pixel (no FMA: the reference multiplies, then adds) are 1472 packed + 145 scalar instructions per thread of
+// 1912, 42 us at four cycles each.  69 us measured (74 before the XCD order, the incremental staging addresses and the
+// straight-line stores of round 4): 0.185 vector instructions per clock and SIMD, which is what this instruction mix reaches
+// here whatever the structure -- 4 or 8 outputs per thread, 4 or 8 waves per SIMD (68.6-69.5 us with DOF_WAVES = 8,
+// DOF_PY = 4 at 63 VGPRs), 24 or 8 LDS reads per tap row, or every wave streaming its own rows through an LDS ring with no
+// barrier at all (a variant built, measured and removed); tools/ubench.hip's packed multiply-add chains reach 0.207 at four
+// waves per SIMD and 0.222 at eight.
 #include "dof.hpp"
 
 #include <utility>
@@ -30,8 +34,12 @@ namespace mirt {
 namespace {
 
 constexpr int DOF_TX = 64;            // outputs per tile row = one wavefront
-constexpr int DOF_WAVES = 4;
-constexpr int DOF_PY = 8;             // vertically adjacent outputs per thread
+#ifndef MIRT_DOF_WAVES
+#define MIRT_DOF_WAVES 4
+#define MIRT_DOF_PY 8
+#endif
+constexpr int DOF_WAVES = MIRT_DOF_WAVES;
+constexpr int DOF_PY = MIRT_DOF_PY;   // vertically adjacent outputs per thread
 constexpr int DOF_TY = DOF_WAVES * DOF_PY;
 constexpr int DOF_MAX_TILE_K = 16;
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -77,10 +85,15 @@ __device__ __forceinline__ void dof_row(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2],
         typedef const __attribute__((address_space(3))) f2 lds_f2;
         lds_float *tn = (lds_float *)(t0 + (RR + 1) * pitch), *tb = tn + boff;
         asm volatile("" : "+v"(tn), "+v"(tb));
+#ifdef MIRT_DOF_DIAG_NOLDS
+#pragma unroll
+        for (int c = 0; c < KT; c++) { nxy[c] = cxy[c] + (f2){ 1.0f, 1.0f }; nz[c] = cz[c]; }      // (timing diagnostic: wrong pictures)
+#else
 #pragma unroll
         for (int c = 0; c < KT; c++) nxy[c] = *(lds_f2 *)(tn + 2 * c);
 #pragma unroll
         for (int c = 0; c < KT; c++) nz[c] = tb[c];
+#endif
     }
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -139,7 +152,23 @@ __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame 
     const int TR = DOF_TY + K - 1;                    // tile rows
     const int TC = DOF_TX + K - 1;                    // tile columns
     const int pitch = KT > 0 ? ((TC * 3 + 1) & ~1) : TC * 3;   // floats per tile row (even for the planar layout: its (r, g) pairs are read as 8-byte words)
-    const int x0 = blockIdx.x * DOF_TX, ty0 = f.y0 + blockIdx.y * DOF_TY;
+    // Workgroup -> tile.  Consecutive workgroup ids go to consecutive XCDs, each with an L2 of its own: with tiles dealt in
+    // row-major order every neighbour of a tile ran on another XCD and each tile's halo (7 of 39 rows, 7 of 71 columns, rounded
+    // out to whole cache lines) came over the fabric once per tile.  So XCD g (= id % 8) takes the g-th eighth of the tiles in
+    // row-major order, id / 8 counting through it: neighbours share an L2 and the halo is fetched once per XCD.
+    int bx, by;
+    {
+        const int tiles_x = (f.W + DOF_TX - 1) / DOF_TX, tiles = tiles_x * ((f.y1 - f.y0 + DOF_TY - 1) / DOF_TY);
+#ifndef MIRT_DOF_ROW_MAJOR
+        const int per = (tiles + 7) >> 3, t = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+        if (t >= tiles) return;                          // (the grid is 8 * per workgroups; a whole workgroup leaves together)
+#else
+        const int t = blockIdx.x;
+        if (t >= tiles) return;
+#endif
+        by = t / tiles_x; bx = t - by * tiles_x;
+    }
+    const int x0 = bx * DOF_TX, ty0 = f.y0 + by * DOF_TY;
 
     // stage: tile(r, c) = pixelColours[(ty0 + zlo + r) * W + (x0 + zlo + c)] by FLAT index, as the reference addresses
     // it (a column outside the row wraps into the neighbouring row); 0 outside the frame / the rows rendered.
@@ -157,22 +186,24 @@ __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame 
         typedef float f3 __attribute__((ext_vector_type(3)));
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(f.rgb + lo), 0, (int)((hi - lo) * 4), 0x00020000);
         f3 v[ROWS][COLS];
+        // (one 64-bit product for the thread's first row; the rows below it are DOF_WAVES frame rows further on, the column groups 64
+        // pixels: 32-bit additions of a uniform stride and a constant -- the sums wrap exactly as the offsets themselves would)
+        const uint32_t off0 = (uint32_t)((3 * ((long long)(ty0 + zlo + (int)threadIdx.y) * f.W + (x0 + zlo)) - lo) * 4) + threadIdx.x * 12u;
+        const uint32_t row_step = (uint32_t)(DOF_WAVES * 12) * (uint32_t)f.W;
 #pragma unroll
         for (int j = 0; j < ROWS; j++) {
-            const int r = threadIdx.y + j * DOF_WAVES;
-            const long long src = 3 * ((long long)(ty0 + zlo + r) * f.W + (x0 + zlo)) - lo;     // first float of the tile row, relative to `lo`
-            const uint32_t row_off = (uint32_t)(src * 4);
+            const uint32_t row_off = off0 + (uint32_t)j * row_step;
 #pragma unroll
-            for (int k = 0; k < COLS; k++) {
-                const int c = threadIdx.x + k * DOF_TX;
-                v[j][k] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(row_off + (uint32_t)c * 12u), 0, 0));
-            }
+            for (int k = 0; k < COLS; k++)
+                v[j][k] = __builtin_bit_cast(f3, __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(row_off + (uint32_t)(k * DOF_TX * 12)), 0, 0));
         }
         // (every load is issued here, before the first store: a load sunk into a guarded store would wait for memory alone)
 #pragma unroll
         for (int j = 0; j < ROWS; j++)
 #pragma unroll
             for (int k = 0; k < COLS; k++) asm volatile("" : "+v"(v[j][k]));
+        // the thread's first (r, g) pair and first blue; everything else sits at compile-time distances from them
+        float *const pxy = tile + threadIdx.y * pitch + 2 * threadIdx.x, *const pz = tile + threadIdx.y * pitch + 2 * TC + threadIdx.x;
 #pragma unroll
         for (int j = 0; j < ROWS; j++) {
             const int r = threadIdx.y + j * DOF_WAVES;
@@ -181,8 +212,8 @@ __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame 
                 const int c = threadIdx.x + k * DOF_TX;
                 // (only the last row group and the last column group can fall outside the tile: the rest is unconditional)
                 if (((j + 1) * DOF_WAVES <= DOF_TY + KT - 1 || r < TR) && ((k + 1) * DOF_TX <= DOF_TX + KT - 1 || c < TC)) {
-                    *reinterpret_cast<f2 *>(tile + r * pitch + 2 * c) = (f2){ v[j][k].x, v[j][k].y };
-                    tile[r * pitch + 2 * TC + c] = v[j][k].z;
+                    *reinterpret_cast<f2 *>(pxy + j * DOF_WAVES * pitch + 2 * k * DOF_TX) = (f2){ v[j][k].x, v[j][k].y };
+                    pz[j * DOF_WAVES * pitch + k * DOF_TX] = v[j][k].z;
                 }
             }
         }
@@ -254,13 +285,31 @@ __global__ __launch_bounds__(DOF_TX * DOF_WAVES) void k_dof_tile(const DofFrame 
             }
         }
     }
+    if constexpr (KT > 0) {
+        // Straight-line stores: the surface's rows up to y1 as a range-checked buffer -- a store whose offset lies beyond it is dropped --,
+        // and a pixel that is not to be written (beyond the band; a border pixel of a surface that keeps its border) gets such an
+        // offset.  (With a branch per output the eight stores cost 300 scalar instructions of exec-mask bookkeeping per wave.)
+        const long long span = (long long)(f.y1 - f.row_origin) * f.pitch_words * 4;      // < 2^31 (launch_dof)
+        const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc((void *)f.xrgb, 0, (int)span, 0x00020000);
+        const bool xin = x >= 1 && x < f.W - 1;
+        const uint32_t off0 = ((uint32_t)(yb - f.row_origin) * (uint32_t)f.pitch_words + (uint32_t)x) * 4u, step = (uint32_t)f.pitch_words * 4u;
 #pragma unroll
-    for (int p = 0; p < DOF_PY; p++) {
-        const int y = yb + p;
-        if (y >= f.y1) break;
-        uint32_t *out = f.xrgb + (size_t)(y - f.row_origin) * f.pitch_words + x;
-        if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1) *out = pack_xrgb(fin[p]);   // interior only (:618-620), PutPixelSDL (:646)
-        else if (f.clear_border) *out = 0u;
+        for (int p = 0; p < DOF_PY; p++) {
+            const int y = yb + p;
+            const bool in = xin && y >= 1 && y < f.H - 1;                                 // interior only (:618-620)
+            const uint32_t word = in ? pack_xrgb(fin[p]) : 0u;                            // PutPixelSDL (:646); a cleared border otherwise
+            const bool put = y < f.y1 && (in || f.clear_border);
+            __builtin_amdgcn_raw_buffer_store_b32(word, osrc, (int)(put ? off0 + (uint32_t)p * step : 0xFFFFFFFFu), 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < DOF_PY; p++) {
+            const int y = yb + p;
+            if (y >= f.y1) break;
+            uint32_t *out = f.xrgb + (size_t)(y - f.row_origin) * f.pitch_words + x;
+            if (x >= 1 && x < f.W - 1 && y >= 1 && y < f.H - 1) *out = pack_xrgb(fin[p]);   // interior only (:618-620), PutPixelSDL (:646)
+            else if (f.clear_border) *out = 0u;
+        }
     }
 }
 
@@ -304,9 +353,10 @@ void launch_dof(const DofFrame &d, hipStream_t stream)
     const int rows = d.y1 - d.y0;
     if (rows <= 0 || d.W <= 0) return;
     if (d.K <= DOF_MAX_TILE_K) {
-        const dim3 grid((d.W + DOF_TX - 1) / DOF_TX, (rows + DOF_TY - 1) / DOF_TY), block(DOF_TX, DOF_WAVES);
-        // (k_dof_tile<8> addresses the frame with 32-bit byte offsets)
-        if (d.K == 8 && 12LL * d.W * d.H < (1LL << 31)) hipLaunchKernelGGL(k_dof_tile<8>, grid, block, dof_tile_lds_bytes(8), stream, d);
+        const int tiles = ((d.W + DOF_TX - 1) / DOF_TX) * ((rows + DOF_TY - 1) / DOF_TY);
+        const dim3 grid(((tiles + 7) / 8) * 8), block(DOF_TX, DOF_WAVES);      // (eight runs of tiles, one per XCD: see k_dof_tile)
+        // (k_dof_tile<8> addresses the frame and the surface with 32-bit byte offsets)
+        if (d.K == 8 && 12LL * d.W * d.H < (1LL << 31) && 4LL * (d.y1 - d.row_origin) * d.pitch_words < (1LL << 31) && d.row_origin <= d.y0) hipLaunchKernelGGL(k_dof_tile<8>, grid, block, dof_tile_lds_bytes(8), stream, d);
         else hipLaunchKernelGGL(k_dof_tile<0>, grid, block, dof_tile_lds_bytes(d.K), stream, d);
     } else {
         hipLaunchKernelGGL(k_dof_direct, dim3((d.W + 255) / 256, rows), dim3(256), 0, stream, d);
