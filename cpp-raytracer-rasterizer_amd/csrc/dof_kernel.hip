@@ -23,7 +23,10 @@
 // here whatever the structure -- 4 or 8 outputs per thread, 4 or 8 waves per SIMD (68.6-69.5 us with DOF_WAVES = 8,
 // DOF_PY = 4 at 63 VGPRs), 24 or 8 LDS reads per tap row, or every wave streaming its own rows through an LDS ring with no
 // barrier at all (a variant built, measured and removed); tools/ubench.hip's packed multiply-add chains reach 0.207 at four
-// waves per SIMD and 0.222 at eight.
+// waves per SIMD and 0.23 at eight.  Two more A/B builds of round 4: the tap rows never read from LDS (wrong pictures) 64 us --
+// the reads cost 5 us --, and the same sums with one-lane v_mul_f32 / v_add_f32 (two cycles each when every operand is a vector
+// register, profiles/r04_ubench.txt) 70 us for 55 M instructions instead of 31 M: packed or not, the pipes deliver ~51 T
+// multiplies-or-adds per second here of the ~70 T the probes reach.
 #include "dof.hpp"
 
 #include <utility>
@@ -85,15 +88,10 @@ __device__ __forceinline__ void dof_row(f2 (&fxy)[DOF_PY], f2 (&fz)[DOF_PY / 2],
         typedef const __attribute__((address_space(3))) f2 lds_f2;
         lds_float *tn = (lds_float *)(t0 + (RR + 1) * pitch), *tb = tn + boff;
         asm volatile("" : "+v"(tn), "+v"(tb));
-#ifdef MIRT_DOF_DIAG_NOLDS
-#pragma unroll
-        for (int c = 0; c < KT; c++) { nxy[c] = cxy[c] + (f2){ 1.0f, 1.0f }; nz[c] = cz[c]; }      // (timing diagnostic: wrong pictures)
-#else
 #pragma unroll
         for (int c = 0; c < KT; c++) nxy[c] = *(lds_f2 *)(tn + 2 * c);
 #pragma unroll
         for (int c = 0; c < KT; c++) nz[c] = tb[c];
-#endif
     }
     asm volatile("" ::: "memory");
 #pragma unroll
