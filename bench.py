@@ -46,9 +46,11 @@ INDIRECT = (0.2, 0.2, 0.2)                                                    # 
 RASTER_FLOP_PER_PIXEL = 109.0   # interpolation of the winning fragment + PixelShader with one light, as written (rasteriser.cpp:549-589, 661-662)
 FLOP_PER_TEST = 60.0          # 57 add/mul + 3 div as written in raytracer.cpp:216-239
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: vector FP32 peak (counts FMA as 2; this path may not fuse)
-# what bit-exact parity leaves reachable: no FMA contraction (half the flops per instruction); packed v_pk_* where two rays share
-# a lane (78.6), one flop per lane and instruction otherwise (39.3)
-PEAK_REACHABLE_TFLOPS = {"no_fma_packed": 78.6, "no_fma_scalar": 39.3}
+# what bit-exact parity leaves reachable: no FMA contraction, i.e. half the peak: 78.6 -- with packed v_pk_* (two flops per lane every
+# four cycles) or with one-lane v_mul / v_add on vector registers (one flop per lane every two cycles: tools/ubench.hip measures 0.43 of
+# the nominal 0.5 such instructions per clock and SIMD, and 0.232 packed ones of 0.25).  A one-lane instruction with a scalar-register
+# operand issues every four cycles (39.3): what "no_fma_scalar" stood for through round 3, when only that case had been probed.
+PEAK_REACHABLE_TFLOPS = {"no_fma_packed": 78.6, "no_fma_one_lane_vector_operands": 78.6, "no_fma_one_lane_scalar_operand": 39.3}
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak
 ISSUE_CEILING = 0.24          # issue ceiling of FOUR-CYCLE vector instructions, wave-instr / clk / SIMD (profiles/r04_ubench.txt): the fallback
 ROUND = "r04"                 # which committed profiles/ files `traffic` and `valu_issue` are read from
