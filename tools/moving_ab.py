@@ -25,22 +25,23 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
         W, H, n, size, seed, reps, frames = 1920, 1080, 100000, 0.05, 1, 5, 2000
     mirt.scene_upload(mirt.scene_soup(seed, n, size))
     views = [mirt.make_view((0, 0, -2), mirt.rot_from_yaw(0.001 * i, 1.0), H / 2.0, W, H) for i in range(64)]
-    bufs = [DeviceArray((H, W), np.uint32) for _ in range(4)]
+    flights = [int(x) for x in os.environ.get("MIRT_AB_FLIGHT", "4,1").split(",")]
+    bufs = [DeviceArray((H, W), np.uint32) for _ in range(max(flights))]
     res = []
-    for in_flight in (4, 1):
+    for in_flight in flights:
         mirt.set_frames_in_flight(in_flight)
         best = 1e9
         for rep in range(reps):
             for i in range(frames // 10):
-                mirt.raytrace_device(views[i & 63], LIGHT, IND, mirt.RT_BINNED, 0, H, 0, bufs[i & 3].ptr, W * 4)
+                mirt.raytrace_device(views[i & 63], LIGHT, IND, mirt.RT_BINNED, 0, H, 0, bufs[i % in_flight].ptr, W * 4)
             mirt.sync()
             t0 = time.perf_counter()
             for i in range(frames):
-                mirt.raytrace_device(views[i & 63], LIGHT, IND, mirt.RT_BINNED, 0, H, 0, bufs[i & 3].ptr, W * 4)
+                mirt.raytrace_device(views[i & 63], LIGHT, IND, mirt.RT_BINNED, 0, H, 0, bufs[i % in_flight].ptr, W * 4)
             mirt.sync()
             best = min(best, (time.perf_counter() - t0) / frames)
         res.append(best * 1e6)
-    print("%-10s %-40s frame %8.2f us with 4 in flight, %8.2f us with 1 (camera moving, best of %d x %d)" % (work, tag.split("/")[-1], res[0], res[1], reps, frames), flush=True)
+    print("%-10s %-40s frame %s us with %s in flight (camera moving, best of %d x %d)" % (work, tag.split("/")[-1], " / ".join("%.2f" % r for r in res), " / ".join(str(f) for f in flights), reps, frames), flush=True)
     mirt.shutdown()
     sys.exit(0)
 
