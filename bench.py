@@ -635,6 +635,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
             "frames_per_step": fps_step, "ms_per_frame": round(ms_frame, 5), "timed_region_s": round(dt, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "data": "synthetic",
             "frames_per_s": round(nframes / dt, 3), "frames_in_flight": in_flight,
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
             "camera": ("orbit: yaw += %g rad per frame, %d views" % (ORBIT_STEP, nviews)) if moving else "static",
             "kernel_ms_rank0": {k: round(v, 5) for k, v in kernel_ms.items()},
         }
