@@ -766,6 +766,32 @@ def test_rt_depth_of_field_bands(oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("K", [8, 5])
+def test_depth_of_field_into_a_band_buffer_with_its_own_pitch(oracle, K):
+    """A rank of a sharded frame resolves its band into a buffer that starts at the band's first row (row_origin = y0) and may be
+    wider than the frame (pitch > width): the blur's stores address that buffer (k_dof_tile<8>: range-checked against ITS extent),
+    words beyond the frame's width and rows beyond the band stay what they were."""
+    tris = mirt.scene_soup(33, 900, 0.12)
+    W, H, FL, pitch_words = 150, 96, 1.3, 157
+    cam, rot, focal = (0, 0, -2), oracle.rot_from_yaw(0.05, 1.0), 60.0
+    ref = oracle.raytrace(tris, cam, rot, focal, W, H, DEFAULT_LIGHT)
+    want = oracle.dof(ref["rgb"], _rt_focal_distances(ref, FL), K, xrgb=np.full((H, W), 0x66, np.uint32))
+    mirt.scene_upload(tris)
+    view = mirt.make_view(cam, rot, focal, W, H)
+    mirt.set_depth_of_field(K, FL)
+    try:
+        for (y0, y1) in [(0, 40), (40, 77), (77, 96)]:
+            rows = y1 - y0
+            surf = _DeviceWords(pitch_words, rows + 2, 0x66)               # (two rows of slack behind the band)
+            mirt.raytrace_device(view, DEFAULT_LIGHT, (0.2, 0.2, 0.2), mirt.RT_AUTO, y0, y1, y0, surf.ptr, pitch_words * 4)
+            got = surf.read()
+            surf.free()
+            assert np.array_equal(got[:rows, :W], want[y0:y1]), "band [%d, %d)" % (y0, y1)
+            assert (got[:rows, W:] == 0x66).all() and (got[rows:] == 0x66).all()
+    finally:
+        mirt.set_depth_of_field(0)
+
+
 @pytest.mark.parametrize("K,FL,W,H", [(8, 1.9, 320, 240), (3, 3.0, 97, 61)])
 def test_raster_depth_of_field(oracle, K, FL, W, H):
     """Rasteriser CalculateDOF (rasteriser.cpp:494-513) over focalDistances = |pPos3d - cameraPos| - FOCAL_LENGTH of the
