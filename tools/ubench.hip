@@ -117,6 +117,14 @@ __global__ __launch_bounds__(256) void k_lds(float *out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// what the two counters tick at: one wave spins until s_memtime has advanced by `ticks`, the host times it with events
+__global__ void k_spin(unsigned long long ticks, unsigned long long *out)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
+    out[0] = __builtin_amdgcn_s_memtime() - t0; out[1] = __builtin_amdgcn_s_memrealtime() - r0;
+}
+
 template <typename F>
 float time_ms(F launch, int reps = 5)
 {
@@ -147,6 +155,15 @@ int main()
     const int iters = 20000;
     unsigned long long *clk;                 // [mode][ticks, 100 MHz ticks] of workgroup 0 of the latest launch
     CHECK(hipHostMalloc((void **)&clk, sizeof(unsigned long long) * 128));
+    {
+        const unsigned long long ticks = 100000000ull;
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, 0, 1000ull, clk);      // (warm-up)
+        CHECK(hipDeviceSynchronize());
+        const float ms = time_ms([&] { hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, 0, ticks, clk); }, 1);
+        CHECK(hipDeviceSynchronize());
+        printf("counters: %llu s_memtime ticks and %llu s_memrealtime ticks in %.3f ms by hipEvents -> s_memtime %.1f MHz, s_memrealtime %.1f MHz\n",
+               clk[0], clk[1], ms, clk[0] / (ms * 1e3), clk[1] / (ms * 1e3));
+    }
     for (int bpc : { 1, 2, 4, 8 }) {       // blocks of 256 threads per CU = waves per SIMD
         const int grid = cus * bpc;
         const double lanes = (double)grid * 256;
