@@ -35,7 +35,7 @@ struct RtTileFrame {
 };
 __global__ void k_tile_tables(const RtTileFrame);
 template <int TW, bool AA> __global__ void k_rt_tile2(const RtTileFrame);
-__global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
+template <int WG> __global__ void k_bin_pairs(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
 struct TilePairRec { uint32_t tile, beg, nA, nB; };
 constexpr int ORDER_CLASSES = 8, ORDER_GROUPS = 8;
 struct RtTraceFrame {                            // (rt_trace.hip)
@@ -556,9 +556,16 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
     bs.bucket_cnt = bcnt; bs.nbuckets = nbuckets; bs.bucket_shift = bucket_sort_shift(bs.nbins);
     const size_t bin_lds = (size_t)nbuckets * sizeof(uint32_t);
     {   // k_bin_pairs: ~52 KB of static LDS + up to 32 KB of bucket counters: past the 64 KB a launch may use by default
-        static const bool once = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024); return true; }();
+        static const bool once = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_pairs<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_pairs<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
+            return true; }();
         (void)once;
     }
+    // workgroups of 256 threads where the frame's kernels overlap with its neighbours' -- three or four frames in flight, a scene small
+    // enough for that to matter --, of 512 for the large scenes and for the frame that runs alone, whose latency they serve (rt_binned.hip)
+    static const int bin_wg_env = [] { const char *e = getenv("MIRT_BIN_WG"); return e ? atoi(e) : 0; }();
+    const int bin_wg = (bin_wg_env == 256 || bin_wg_env == 512) ? bin_wg_env : ((g.n < 400000 && g.in_flight >= 3) ? 256 : 512);
     if (guess) {
         // room for half as many pairs again as the last frame seen produced; growing needs this stream idle (rare)
         const size_t want = (size_t)S.known_pairs + S.known_pairs / 2 + 4096;
@@ -577,7 +584,8 @@ int bin_pass(RtScratch &S, BinSet bs, const OriginRow *cam_tab, const OriginRow 
         if (attempt) HIP_TRY(hipMemsetAsync(counter, 0, 4, g.stream));
         if (attempt || S.bucket_dirty) HIP_TRY(hipMemsetAsync(S.d_bucket, 0, sizeof(uint32_t) * 3 * (size_t)S.cap_buckets, g.stream));
         S.bucket_dirty = true;                               // bucket counts pending until k_bs_local has consumed them
-        hipLaunchKernelGGL(k_bin_pairs, bin_grid, dim3(BIN_WG), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
+        if (bin_wg == 256) hipLaunchKernelGGL(k_bin_pairs<256>, bin_grid, dim3(256), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
+        else hipLaunchKernelGGL(k_bin_pairs<512>, bin_grid, dim3(512), bin_lds, g.stream, g.d_tris, cam_tab, light_tab, g.n, bs, pairs);
         if (!fresh) break;
         if (guess) {
             // no sync: k_bs_scatter stores the count into a pinned word behind the kernel and a later frame picks it up

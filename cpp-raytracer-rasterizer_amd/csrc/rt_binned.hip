@@ -349,7 +349,8 @@ __global__ __launch_bounds__(SEL_WG) void k_select_faces(const float *__restrict
 // What the flattened bin-by-bin tests need of a direct item, in LDS: A2, Bu, Bv and box = {lou, hiu, lov, hiv}, one array per
 // field (neighbouring lanes read neighbouring items: 16-byte stride, where a 64-byte record put them on the same banks).
 
-__global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
+template <int WG>
+__global__ __launch_bounds__(WG) void k_bin_pairs(const float *__restrict__ tris15, const OriginRow *__restrict__ cam_tab,
                                                    const OriginRow *__restrict__ light_tab, int n, BinSet bs, BinPairs out)
 {
     // pairs per bucket (bin >> bucket_shift) for the sort that follows (bin_bucket_sort.hip): bs.bucket_cnt != NULL
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
     const int nwork = ncam + (faces_listed ? (int)s_first[nrest] : nchunks * nrest);
     if (threadIdx.x == 0) { s_fill = 0u; s_valid = (uint32_t)BIN_PAIR_BUF; }
     if (bs.bucket_cnt)
-        for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += BIN_WG) s_bucket[b] = 0u;
+        for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += WG) s_bucket[b] = 0u;
 
     // hands the staged pairs over to the global list (called by all threads)
     auto flush = [&]() {
@@ -402,14 +403,14 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
         if (threadIdx.x == 0 && staged) s_base = atomicAdd(&bs.counters[0], staged);
         __syncthreads();
         const uint32_t base = s_base;
-        for (uint32_t i = threadIdx.x; i < staged; i += BIN_WG) {
+        for (uint32_t i = threadIdx.x; i < staged; i += WG) {
             const uint32_t at = base + i;
             if (at < out.cap) { out.keys[at] = s_keys[i]; out.vals[at] = s_vals[i]; }
             if (bs.bucket_cnt) atomicAdd(&s_bucket[s_keys[i] >> bs.bucket_shift], 1u);
         }
         __syncthreads();
         if (bs.bucket_cnt && staged)
-            for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += BIN_WG) {
+            for (uint32_t b = threadIdx.x; b < bs.nbuckets; b += WG) {
                 const uint32_t c = s_bucket[b];
                 if (c) { atomicAdd(&bs.bucket_cnt[b], c); s_bucket[b] = 0u; }
             }
@@ -566,19 +567,19 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
         { const unsigned long long md = __ballot(kind == 1); if (lane == 0) atomicAdd(&bs.counters[10], (uint32_t)__popcll(md)); }
 #endif
         STAMP(st_prefix)
-        // ---- flattened bin-by-bin tests: thread t of a round takes tests t, t + BIN_WG, ... ----
+        // ---- flattened bin-by-bin tests: thread t of a round takes tests t, t + WG, ... ----
         constexpr int TPT = BIN_TESTS_PER_THREAD;
-        for (uint32_t r0 = 0; r0 < T; r0 += BIN_WG * TPT) {
+        for (uint32_t r0 = 0; r0 < T; r0 += WG * TPT) {
 #ifdef MIRT_BIN_STAMPS
             st_nrounds++;
 #endif
             __syncthreads();                          // s_pre written / the previous round's appends counted
-            if (s_fill + (uint32_t)(BIN_WG * TPT) > (uint32_t)BIN_PAIR_BUF) flush();
+            if (s_fill + (uint32_t)(WG * TPT) > (uint32_t)BIN_PAIR_BUF) flush();
             bool pass[TPT];
             uint32_t key[TPT], val[TPT];
 #pragma unroll
             for (int q = 0; q < TPT; q++) {
-                const uint32_t t = r0 + (uint32_t)(q * BIN_WG) + threadIdx.x;
+                const uint32_t t = r0 + (uint32_t)(q * WG) + threadIdx.x;
                 pass[q] = false; key[q] = 0; val[q] = 0;
                 if (t < T) {
                     uint32_t lo = 0, hi = 256;            // the item whose range [s_pre[i], s_pre[i+1]) holds t
@@ -616,14 +617,14 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
                 for (int q = 0; q < TPT; q++)
                     if (pass[q]) {
                         const uint32_t at = at0 + off[q] + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull));
-                        s_keys[at] = key[q]; s_vals[at] = val[q];         // fits: the round started with room for BIN_WG * TPT
+                        s_keys[at] = key[q]; s_vals[at] = val[q];         // fits: the round started with room for WG * TPT
                     }
             }
         }
 
         STAMP(st_rounds)
         // ---- huge items: the wave walks them one at a time, pairs into the same LDS buffer ----
-        __syncthreads();                              // no flattened round (which counts on its BIN_WG * TPT free slots) is still appending
+        __syncthreads();                              // no flattened round (which counts on its WG * TPT free slots) is still appending
         {
             BinLargeSink sink = { s_keys, s_vals, &s_fill, &s_valid, &bs.counters[0], out, bs.bucket_cnt, bs.bucket_shift };
             for (unsigned long long ml = __ballot(kind == 2); ml;) {
@@ -655,5 +656,13 @@ __global__ __launch_bounds__(BIN_WG) void k_bin_pairs(const float *__restrict__ 
                st_setup, st_prefix, st_rounds, st_nrounds, st_huge, st_flush);
 #endif
 }
+
+// Two shapes of workgroup: 512 threads -- a work item's 256 triangles are set up by the first four waves, the flattened tests run on
+// all eight -- and 256, where every wave sets up and tests.  The smaller one holds no idle waves during the set-up, which leaves the
+// frames in flight beside it more of the chip (100 k triangles at 1080p: 63.8 against 65.7 us per frame with four in flight, 122
+// against 118 us with one); the larger one halves the rounds of the tests, which is what a 1 M-triangle frame wants (1.15 against
+// 1.23 ms at 8K).  mirt_capi.hip picks by the size of the scene and the frames in flight (MIRT_BIN_WG overrides).
+template __global__ void k_bin_pairs<512>(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
+template __global__ void k_bin_pairs<256>(const float *, const OriginRow *, const OriginRow *, int, BinSet, BinPairs);
 
 }  // namespace mirt

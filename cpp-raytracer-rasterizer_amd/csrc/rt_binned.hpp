@@ -32,8 +32,8 @@ namespace mirt {
 constexpr int ORDER_STRIPE_SHIFT = MIRT_ORDER_STRIPE_SHIFT;   // log2 of the tile rows per stripe dealt to one XCD group (rt_trace.hip: k_tile_order)
 constexpr int BIN_TILE = 8;            // camera bins are 8x8 pixels = one wave64
 constexpr int BIN_COARSE = 8;          // coarse cell = 8x8 fine bins (the three-level walk of huge items, rt_binned.hip)
-constexpr int BIN_WG = 512;            // threads of a k_bin_pairs workgroup: a work item's 256 triangles are set up by the first four waves, the
-                                       // flattened bin tests and the flushes run on all eight (two waves per SIMD issue twice as fast as one)
+// (k_bin_pairs<WG>: workgroups of 512 threads -- a work item's 256 triangles are set up by the first four waves, the flattened bin tests
+// and the flushes run on all eight -- or of 256, every wave doing both: rt_binned.hip says which when)
 constexpr int CUBE_BINS_MIN = 64;      // per-face light-cube grid is B x B; B = 64 by default (128 / 256 selectable)
 constexpr int MAX_BIN_FRAMES = 1 + 6 * MIRT_MAX_LIGHTS;
 
