@@ -132,7 +132,8 @@ def measured_traffic(workload, kernel_prefixes, per_frame=False):
     if per_frame:
         ks = {k: v for k, v in ks.items() if v.get("launches", 0) > 2}
         most = max((v["launches"] for v in ks.values()), default=0)
-        tot = sum((v["fetch_bytes"] + v["write_bytes"]) * min(1.0, v["launches"] / most) for v in ks.values()) if most else 0
+        # (weights as in measured_valu_per_frame: nearly as often as the kernel launched most = once per frame of the loop)
+        tot = sum((v["fetch_bytes"] + v["write_bytes"]) * (1.0 if v["launches"] >= 0.75 * most else v["launches"] / most) for v in ks.values()) if most else 0
     else:
         tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in ks.values())
     return int(tot) or None
@@ -141,12 +142,14 @@ def measured_traffic(workload, kernel_prefixes, per_frame=False):
 def one_instantiation(kernels):
     """Of the instantiations of one kernel template a pass saw (k_rt_trace2<false, false> in the frames of the loop, <false, true> --
     the one that keeps statistics -- in the profiled frames) only the one launched most: they are the same launch counted twice."""
-    best = {}
+    best, total = {}, {}
     for k, v in kernels.items():
         base = k.split("<")[0]
+        total[base] = total.get(base, 0) + v.get("launches", 0)
         if base not in best or v.get("launches", 0) > best[base][1].get("launches", 0):
             best[base] = (k, v)
-    return {k: v for k, v in best.values()}
+    # (the counters of the instantiation launched most, the launches of all of them: how often the KERNEL ran per frame)
+    return {k: dict(v, launches=total[k.split("<")[0]]) if "launches" in v else v for k, v in best.values()}
 
 
 def measured_valu_instructions(workload, kernel_prefix):
@@ -230,7 +233,9 @@ def measured_valu_per_frame(workload):
     if not per_frame:
         return None
     most = max(v["launches"] for v in per_frame)
-    return sum(float(v["SQ_INSTS_VALU"]) * min(1.0, v["launches"] / most) for v in per_frame)
+    # (a kernel launched nearly as often as the one launched most runs once per frame of the loop: the pass's warm-up frames, whose view
+    # stands still, skip the binning kernels; one launched rarely -- a light-cube build -- counts by its share)
+    return sum(float(v["SQ_INSTS_VALU"]) * (1.0 if v["launches"] >= 0.75 * most else v["launches"] / most) for v in per_frame)
 
 
 def cpu_baseline(kind, tris, culled, W, H, cam, rot, focal, budget_s=12.0, samples=1, jitter=None, aa=1):
