@@ -1953,6 +1953,10 @@ static int raster_enqueue(const mirt_view *view, const mirt_light *lights, int n
     f.focal_plane = g.dof_focal;
     if ((rc = raster_scratch_ensure(scratch, g.n, view->width, y1 - y0))) return fail(rc, "raster scratch allocation failed");
     g.raster_since_sync = true;
+    {
+        static const int edge_env = [] { const char *e = getenv("MIRT_EDGE_SEGMENTS"); return e ? atoi(e) : -1; }();
+        f.edge_segments = edge_env >= 0 ? edge_env : (g.in_flight <= 2 ? 1 : 0);       // (2: tests -- a spoilt prediction in every chain)
+    }
     if ((rc = launch_raster(f, scratch, g.scene_version * 0x9E3779B97F4A7C15ull + g.cull_version, g.stream, g.profiling ? &g.ev[EV_K0] : nullptr,
                             g.profiling ? g.ev_used : nullptr)))
         return fail(rc, "rasteriser launch failed: %s", hipGetErrorString(hipGetLastError()));

@@ -88,8 +88,43 @@ struct RasterFrame {
     int32_t *index;
     float *fd;               // nullable: focalDistances = distance(pPos3d, cameraPos) - FOCAL_LENGTH of the owner fragment (rasteriser.cpp:563-565), 0 where nothing was drawn
     float focal_plane;       // FOCAL_LENGTH (:31)
+    int edge_segments;       // k_raster_edges_lds: the edge chains as 64 predicted-and-checked segments each (one frame at a time: latency) or as one walk
     RasterScratch scratch;
 };
+
+// `cur` after n more of the reference's `current += step` (:632-635) WITHOUT doing them one by one -- a prediction; the caller
+// checks it against the additions themselves (see k_raster_edges_lds).  While the sum stays inside one binade its values lie on
+// that binade's grid (spacing u), and adding the same `step` to a grid point x rounds to x + q with one and the same multiple q
+// of u: round-to-nearest moves x + step to the grid point nearest to it, which does not depend on x -- except when step falls
+// exactly half-way between two grid points, where ties-to-even makes the FIRST such addition depend on x's parity and all later
+// ones (x even by then) agree.  So: three real additions (all inside one binade: the last two's mantissas differ by q in units
+// of u), then as many steps as keep the mantissa at least one unit inside the binade's ends at once, then real
+// additions again across the boundary.  Zeros, subnormals, infinities and NaNs only ever see real additions.
+__device__ __forceinline__ float edge_advance(float cur, float step, int n)
+{
+    while (n > 0) {
+        const float c1 = cur + step;
+        if (--n == 0) return c1;
+        const float c2 = c1 + step;
+        if (--n == 0) return c2;
+        const float c3 = c2 + step;
+        --n;
+        cur = c3;
+        // (all three on the binade's grid: c2 = c1 + step with c1 OFF the grid -- the addition that entered the binade -- may be odd,
+        // and then a half-way step moves it by one unit more or less than it moves the even sums that follow)
+        const uint32_t b1 = __float_as_uint(c1), b2 = __float_as_uint(c2), b3 = __float_as_uint(c3), ex = b3 & 0x7F800000u;
+        if (n > 0 && (((b1 ^ b3) | (b2 ^ b3)) & 0xFF800000u) == 0u && ex != 0u && ex != 0x7F800000u) {
+            const int m3 = (int)(b3 & 0x7FFFFFu), d = m3 - (int)(b2 & 0x7FFFFFu);
+            int i = n;                                                  // (d == 0: the sum no longer moves)
+            if (d > 0) i = (0x7FFFFE - m3) / d;
+            else if (d < 0) i = (m3 - 1) / -d;
+            i = max(min(i, n), 0);
+            cur = __uint_as_float(b3 + (uint32_t)(i * d));
+            n -= i;
+        }
+    }
+    return cur;
+}
 
 int raster_scratch_ensure(RasterScratch &s, int n, int W, int band_rows);
 void raster_scratch_free(RasterScratch &s);

@@ -331,7 +331,47 @@ __global__ __launch_bounds__(1024) void k_raster_edges_lds(const RasterFrame f, 
     const EdgeWalk w0 = edge_walk(s, 0), w1 = edge_walk(s, 1), w2 = edge_walk(s, 2);
 
     const int tid = threadIdx.x;
-    if (tid < 64) {                                  // wave 0: lane = channel = edge*5 + field
+    if (f.edge_segments) {
+    // The 15 chains (3 edges x {x, zinv, pos3d.xyz}), one WAVE per chain, each lane a segment of it: lane g starts from the value
+    // edge_advance() predicts for its first step, walks its segment with the reference's own additions and hands its last sum to
+    // lane g + 1, which compares it -- bit for bit -- with the prediction it started from.  Lane 0 starts from the true first
+    // value, so if every comparison holds every stored sample is the one the sequential walk produces; if one fails (a prediction
+    // that is wrong is merely slow, never visible) lane 0 walks the whole chain the old way.  A 4K-tall edge is 2160 dependent
+    // additions, ~9 cycles apart in a wave alone on its SIMD whatever one does to the loop: 16-25 us of the frame's chain for the
+    // twenty triangles of the Cornell box; as 64 segments of 34 it is the predictions' few dozen instructions plus 34 additions:
+    // k_raster_edges_lds 18-19 -> 14.4 us, the 4K frame alone 61.1 -> 56.5 us.  Fifteen busy waves per triangle instead of one get in
+    // the way of the neighbouring frames' kernels, though (four frames in flight: 28.4 against 27.8 us per frame), so the host asks for
+    // segments when at most two frames are in flight (f.edge_segments; MIRT_EDGE_SEGMENTS=0|1 fixes it).
+    {
+        const int wave = tid >> 6, lane = tid & 63, nwaves = (int)blockDim.x >> 6;
+        const int L = ((max(max(w0.cnt, w1.cnt), w2.cnt) + 3) >> 2) << 2;       // samples kept per chain (workgroup-uniform; a shorter edge keeps samples nobody reads)
+        for (int c = wave; c < 3 * SLOT_FIELDS; c += nwaves) {
+            const int e = c / SLOT_FIELDS, fld = c - e * SLOT_FIELDS;
+            const int i = e, j = (e + 1) % 3;
+            const int N = abs(s.y[i] - s.y[j]) + 1;                      // :713
+            const float div = (float)max(N - 1, 1);                      // :622
+            float cur0, step;
+            if (fld == 0) { cur0 = (float)s.x[i]; step = (float)(s.x[j] - s.x[i]) / div; }
+            else if (fld == 1) { cur0 = s.zinv[i]; step = (s.zinv[j] - s.zinv[i]) / div; }
+            else { cur0 = s.p[i][fld - 2]; step = (s.p[j][fld - 2] - s.p[i][fld - 2]) / div; }
+            const EdgeWalk w = (e == 0) ? w0 : (e == 1) ? w1 : w2;
+            // sample k of the chain is its value after k additions; those before the band (k < skip) are walked, not kept (:632-635)
+            const int T = w.skip + L, seg = (T + 63) >> 6, n0 = min(lane * seg, T), n1 = min(n0 + seg, T);
+            float *dst = s_steps + c * stride;                           // sample k lives at dst[k - skip]
+            float start = edge_advance(cur0, step, n0);
+            // (tests: MIRT_EDGE_SEGMENTS=2 spoils one lane's prediction, so that the check fails and the whole-chain walk runs)
+            if (f.edge_segments == 2 && lane == 5 && n0 < T) start = __uint_as_float(__float_as_uint(start) ^ 1u);
+            float cur = start;
+            for (int k = n0; k < n1; k++) { if (k >= w.skip) dst[k - w.skip] = cur; cur += step; }
+            const float handed = __shfl_up(cur, 1);                      // the previous lane's sum after ITS last addition = this lane's first value
+            const bool ok = lane == 0 || n0 >= T || __float_as_uint(handed) == __float_as_uint(start);
+            if (__builtin_amdgcn_ballot_w64(!ok) != 0ull && lane == 0) {
+                cur = cur0;
+                for (int k = 0; k < T; k++) { if (k >= w.skip) dst[k - w.skip] = cur; cur += step; }
+            }
+        }
+    }
+    } else if (tid < 64) {                           // wave 0: lane = channel = edge*5 + field
         const int e = min(tid / SLOT_FIELDS, 2), fld = tid - e * SLOT_FIELDS;
         const int i = e, j = (e + 1) % 3;
         const int N = abs(s.y[i] - s.y[j]) + 1;                      // :713

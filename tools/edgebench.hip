@@ -1,6 +1,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include "../cpp-raytracer-rasterizer_amd/csrc/raster_common.hpp"      // edge_advance
 __global__ __launch_bounds__(256) void k_chain(float *out, long long *cyc, int n, int dstep, int mode)
 {
     extern __shared__ float s[];
@@ -87,8 +88,45 @@ __global__ __launch_bounds__(256) void k_chain(float *out, long long *cyc, int n
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
     if (tid < 12) out[blockIdx.x * 16 + tid] = s[tid + 15 * (n / 2)] + s[tid * n + 7];
 }
+// edge_advance(cur, step, n) against n additions, one thread per random (cur, step, n): how often the prediction is the sum itself.
+// (k_raster_edges_lds checks every prediction it uses, so a miss costs time, not pixels; this says how rare misses are.)
+__device__ unsigned lcg(unsigned &x) { x = x * 1664525u + 1013904223u; return x; }
+__global__ void k_advance_check(unsigned seed, int cases_per_thread, unsigned long long *tally /* [0] cases, [1] misses, [2..] first missed case */)
+{
+    unsigned x = seed ^ (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u;
+    for (int c = 0; c < cases_per_thread; c++) {
+        const unsigned kind = lcg(x) % 5u;
+        float cur, step;
+        const int n = (int)(lcg(x) % 4400u);
+        const float u1 = (float)(lcg(x) >> 8) * (1.0f / 16777216.0f), u2 = (float)(lcg(x) >> 8) * (1.0f / 16777216.0f);
+        if (kind == 0) { cur = (float)(int)(u1 * 8000.0f - 2000.0f); step = (float)(int)(u2 * 8000.0f - 4000.0f) / (float)max(n, 1); }          // x: integer ends
+        else if (kind == 1) { cur = 0.05f + u1; step = (0.05f + u2 - cur) / (float)max(n, 1); }                                              // zinv
+        else if (kind == 2) { cur = u1 * 4.0f - 2.0f; step = (u2 * 4.0f - 2.0f - cur) / (float)max(n, 1); }                                  // a coordinate, through zero
+        else if (kind == 3) { cur = __uint_as_float(lcg(x)); step = __uint_as_float(lcg(x)); }                                             // any bits at all
+        else { cur = u1 * 1024.0f; step = __uint_as_float((lcg(x) & 0x807FFFFFu) | ((100u + lcg(x) % 40u) << 23)); }                        // steps of every size
+        float seq = cur;
+        for (int k = 0; k < n; k++) seq += step;
+        const float got = mirt::edge_advance(cur, step, n);
+        atomicAdd(&tally[0], 1ull);
+        if (__float_as_uint(seq) != __float_as_uint(got) && !(seq != seq && got != got)) {
+            if (atomicAdd(&tally[1], 1ull) == 0ull) { tally[2] = __float_as_uint(cur); tally[3] = __float_as_uint(step); tally[4] = (unsigned long long)n; tally[5] = __float_as_uint(seq); tally[6] = __float_as_uint(got); }
+        }
+    }
+}
+
 int main()
 {
+    {
+        unsigned long long *tally;
+        hipMalloc(&tally, 8 * 8); hipMemset(tally, 0, 8 * 8);
+        hipLaunchKernelGGL(k_advance_check, dim3(1024), dim3(256), 0, 0, 12345u, 16, tally);
+        unsigned long long h[8];
+        hipMemcpy(h, tally, sizeof h, hipMemcpyDeviceToHost);
+        printf("edge_advance against the additions themselves: %llu random (start, step, count <= 4400) cases, %llu predictions off", h[0], h[1]);
+        if (h[1]) printf(" (first: start %08llx step %08llx n %llu: sum %08llx predicted %08llx)", h[2], h[3], h[4], h[5], h[6]);
+        printf("\n");
+        hipFree(tally);
+    }
     float *out; long long *cyc;
     hipMalloc(&out, 4096 * 4); hipMalloc(&cyc, 256 * 8);
     hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 2560 * 60);
