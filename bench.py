@@ -194,7 +194,7 @@ def issue_ceiling(kernel_prefix):
             pass
     names = sorted(k for k in _issue_mix if kernel_prefix in k)
     # (the instantiation the benchmark lines run: no supersampling, no statistics)
-    names.sort(key=lambda k: (k != "mirt::" + kernel_prefix, "<false, false>" not in k, k.endswith("true>")))
+    names.sort(key=lambda k: (k != "mirt::" + kernel_prefix, "<false, false" not in k, "true" in k))
     return float(_issue_mix[names[0]]["ceiling"]) if names else ISSUE_CEILING
 
 

@@ -63,7 +63,7 @@ struct RtTraceFrame {                            // (rt_trace.hip)
     const uint32_t *light_pair_count;
     uint32_t light_pair_cap;
 };
-template <bool AA, bool STATS> __global__ void k_rt_trace2(const RtTraceFrame);
+template <bool AA, bool STATS, int WAVES = 4> __global__ void k_rt_trace2(const RtTraceFrame);
 __global__ void k_prep_select(const float *, int, const BinFrameDesc, const SelectOut);
 __global__ void k_select_faces(const float *, int, const float *, const BinFrameDesc *, OriginRow *, uint32_t *, uint32_t, uint32_t *);
 __global__ void k_tile_order(const uint32_t *, int, int, int, int, uint32_t *, uint32_t, TilePairRec *, uint32_t);
@@ -1134,7 +1134,12 @@ int rt_enqueue_binned(RtFrame &f, const mirt_view *view, RtScratch &S, RtScratch
         if (g.profiling) hipLaunchKernelGGL((k_rt_trace2<true, true>), tgrid, dim3(64), lds, g.stream, tf);
         else hipLaunchKernelGGL((k_rt_trace2<true, false>), tgrid, dim3(64), lds, g.stream, tf);
     } else {
+        // five waves per SIMD (the 96-VGPR instantiation) for the large scenes and for the frame that runs alone, four (98 VGPRs) for
+        // the small scenes' frames in flight: rt_trace.hip says why; MIRT_TR_WAVES5=0|1 fixes the choice
+        static const int waves5_env = [] { const char *e = getenv("MIRT_TR_WAVES5"); return e ? atoi(e) : -1; }();
+        const bool waves5 = waves5_env >= 0 ? (waves5_env != 0) : (g.n >= 400000 || g.in_flight <= 2);
         if (g.profiling) hipLaunchKernelGGL((k_rt_trace2<false, true>), tgrid, dim3(64), lds, g.stream, tf);
+        else if (waves5) hipLaunchKernelGGL((k_rt_trace2<false, false, 5>), tgrid, dim3(64), lds, g.stream, tf);
         else hipLaunchKernelGGL((k_rt_trace2<false, false>), tgrid, dim3(64), lds, g.stream, tf);
     }
     k_end(MIRT_K_TRACE);

@@ -327,8 +327,16 @@ __global__ __launch_bounds__(64) void k_tile_order(const uint32_t *__restrict__ 
 // both filter loops -- a fifth of the scalar stream --, so the frames of a render loop run without them; a frame rendered with
 // profiling on (mirt_set_profiling: the frames whose kernel times bench.py reads) counts.  The hit count -- the frame's shadow rays
 // -- is one atomic per wave and always kept.
-template <bool AA, bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAVES_MIN, MIRT_TR_WAVES))) void k_rt_trace2(const RtTraceFrame tf)
+// ... and FIVE (<= 96 VGPRs) for the instantiation the large scenes' frames run: the 1 M-triangle frame at 8K gains 4-5 % from the fifth
+// wave (1.09 against 1.13-1.17 ms per frame), the 100 k-triangle frame with four in flight loses 2 % to it (65.3 against 63.9 us: five
+// trace waves per SIMD leave the binning kernels of the frames beside it less room), so mirt_capi.hip launches it from 400 k
+// triangles on and for the frame that runs alone (115.6 against 117.6 us).  Asking for 10 KiB of LDS per wave to hold the 96-register
+// code at four waves was tried instead of a second instantiation: 66.7 us per frame -- the LDS the trace waves then sit on is what
+// the binning kernels of the frames beside them need.  (Round 3 and the first half of round 4 "measured" a fifth wave with builds of 98 VGPRs -- which the hardware runs at
+// four, registers being handed out in eights -- or with spills; the kernel fits 96 since the shaded triangles' colours are fetched
+// after the shadow walk instead of being held across it.)
+template <bool AA, bool STATS, int WAVES = MIRT_TR_WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES == 5 ? 5 : MIRT_TR_WAVES_MIN, WAVES))) void k_rt_trace2(const RtTraceFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
     const RtFrame &f = tf.f;
@@ -540,10 +548,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
             const unsigned nhits = (unsigned)(__popcll(hmA) + __popcll(hmB));
             if (hmA | hmB) {
                 const ShadeRow *srA = tf.shade + (biA >= 0 ? biA : 0), *srB = tf.shade + (biB >= 0 ? biB : 0);
-                const float4 nA4 = srA->n, cA4 = srA->col, nB4 = srB->n, cB4 = srB->col;
+                const float4 nA4 = srA->n, nB4 = srB->n;
+                // (the four-wave instantiations fetch the triangles' colours here, beside the normals, and hold them across the shadow
+                // walk: the six registers that put the kernel at 98 and so at four waves per SIMD, which is what the small scenes' frames
+                // in flight want -- see above the kernel)
+                float4 cA4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cB4 = cA4;
+                if constexpr (WAVES != 5) { cA4 = srA->col; cB4 = srB->col; }
                 const v3p pos = join3(posA, posB);
                 const v3p nDir = join3(V3(nA4.x, nA4.y, nA4.z), V3(nB4.x, nB4.y, nB4.z));   // glm::normalize(normal) (:300), per triangle
-                const v3p tcol = join3(V3(cA4.x, cA4.y, cA4.z), V3(cB4.x, cB4.y, cB4.z));
                 v3p result = splat3(V3(0.0f, 0.0f, 0.0f)), result2 = result;
                 for (int k = 0; k < f.nlights; k++) {
                     // DirectLight's term before the shadow test (raytracer.cpp:294-304), both pixels at once
@@ -657,6 +669,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
                     result = add3p(result, D);                     // (:319)
                     if ((k + 1) % f.samples == 0) result2 = add3p(result2, result);   // (:322) after each light's samples
                 }
+                // (the triangles' colours only now: fetched beside the normals they were six registers held across the whole shadow walk,
+                // the two that kept the kernel from a fifth wave per SIMD)
+                if constexpr (WAVES == 5) { cA4 = srA->col; cB4 = srB->col; }
+                const v3p tcol = join3(V3(cA4.x, cA4.y, cA4.z), V3(cB4.x, cB4.y, cB4.z));
                 const v3p Dl = mul3p(result2, tcol);               // (:325-326)
                 const v3p shaded = add3p(avg, mul3p(tcol, add3p(Dl, splat3(ld3(f.indirect)))));   // (:584-591)
                 avg = join3(hitA ? half0(shaded) : half0(avg), hitB ? half1(shaded) : half1(avg));
@@ -716,7 +732,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIRT_TR_WAV
     }
 }
 
-template __global__ void k_rt_trace2<false, false>(const RtTraceFrame);
+template __global__ void k_rt_trace2<false, false>(const RtTraceFrame);         // the frames of the loop: four waves per SIMD ...
+template __global__ void k_rt_trace2<false, false, 5>(const RtTraceFrame);      // ... or five (mirt_capi.hip)
 template __global__ void k_rt_trace2<false, true>(const RtTraceFrame);
 template __global__ void k_rt_trace2<true, false>(const RtTraceFrame);
 template __global__ void k_rt_trace2<true, true>(const RtTraceFrame);

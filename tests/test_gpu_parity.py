@@ -1312,7 +1312,7 @@ print("ok")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knob", ["", "MIRT_LIGHT_SHELLS=1", "MIRT_CAM_SHELLS=1", "MIRT_CUBE_BINS=64", "MIRT_CUBE_BINS=128", "MIRT_BIN_THRESHOLD=100000",
-                                  "MIRT_RASTER_SMALL=0", "MIRT_RASTER_LDS_ROWS=0", "MIRT_HOST_PATH=direct", "MIRT_LAZY_GEO=1", "MIRT_BIN_REUSE=0", "MIRT_LIGHT_SIDE_STREAM=0", "MIRT_SMALL_WGS_PER_CU=1", "MIRT_BIN_WG=512", "MIRT_EDGE_SEGMENTS=0", "MIRT_EDGE_SEGMENTS=2"])
+                                  "MIRT_RASTER_SMALL=0", "MIRT_RASTER_LDS_ROWS=0", "MIRT_HOST_PATH=direct", "MIRT_LAZY_GEO=1", "MIRT_BIN_REUSE=0", "MIRT_LIGHT_SIDE_STREAM=0", "MIRT_SMALL_WGS_PER_CU=1", "MIRT_BIN_WG=512", "MIRT_EDGE_SEGMENTS=0", "MIRT_EDGE_SEGMENTS=2", "MIRT_TR_WAVES5=1"])
 def test_every_environment_variant_matches_the_oracle(knob):
     """Every environment variable that selects a kernel variant or a table geometry in csrc/ (each is read once per process):
     a Cornell frame (tile kernel), a binned soup (transient and cached light tables), a brute-force soup and two rasterised frames

@@ -49,7 +49,7 @@ def test_committed_table_matches_the_kernel_sources_and_feeds_bench():
     path = os.path.join(ROOT, "profiles", "%s_issue_mix.json" % bench.ROUND)
     doc = json.load(open(path))
     assert doc["csrc_sha16"] == bench.csrc_digest(), "profiles/*_issue_mix.json is stale: run tools/issue_mix.py"
-    trace = doc["kernels"]["mirt::k_rt_trace2<false, false>"]
+    trace = next(v for k, v in doc["kernels"].items() if k.startswith("mirt::k_rt_trace2<false, false"))      # (the instantiation the loop's frames run)
     assert trace["valu"] == trace["fast"] + trace["int"] + trace["slow"] + trace["trans"]
     assert 0.23 < trace["ceiling"] < 0.43
     assert bench.issue_ceiling("k_rt_trace2") == pytest.approx(trace["ceiling"])
