@@ -321,14 +321,20 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
 }
 
 template <int TW, bool AA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rt_tile2(const RtTileFrame tf)
+#ifndef MIRT_TILE_WAVES
+#define MIRT_TILE_WAVES 5
+#endif
+// (five waves per SIMD -- 89 VGPRs -- without supersampling; the supersampling instantiation carries a second set of sub-ray state)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AA ? 3 : MIRT_TILE_WAVES, AA ? 4 : MIRT_TILE_WAVES))) void k_rt_tile2(const RtTileFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
     const TileTables tab = tile_tables_load(tf, s_all);
     const long long ntiles = (long long)tf.tiles_x * tf.tiles_y;
     const int waves = blockDim.x >> 6;
-    for (long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6); tile < ntiles; tile += (long long)gridDim.x * waves)
-        tile_body2<TW, AA>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), tab);
+    // (one tile per wave: the launch has a wave for every tile -- mirt_capi.hip --, and written as a loop over a wave's tiles
+    // everything the body computes from the frame's parameters alone stays live across the whole body for a next round that never comes)
+    const long long tile = (long long)blockIdx.x * waves + (threadIdx.x >> 6);
+    if (tile < ntiles) tile_body2<TW, AA>(tf, (int)(tile % tf.tiles_x), (int)(tile / tf.tiles_x), tab);
 }
 
 template __global__ void k_rt_tile2<16, false>(const RtTileFrame);
