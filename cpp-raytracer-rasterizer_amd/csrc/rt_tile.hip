@@ -230,9 +230,8 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
     if (__any(hit0 || hit1)) {
         const v3p pos = join3(pos0, pos1);                                   // the record carried across sub-rays (:243-247)
         const int s0 = bi0 >= 0 ? bi0 : 0, s1 = bi1 >= 0 ? bi1 : 0;
-        const float4 sa0 = tb.shade[2 * s0], sa1 = tb.shade[2 * s0 + 1], sb0 = tb.shade[2 * s1], sb1 = tb.shade[2 * s1 + 1];
+        const float4 sa0 = tb.shade[2 * s0], sb0 = tb.shade[2 * s1];
         const v3p nDir = join3(V3(sa0.x, sa0.y, sa0.z), V3(sb0.x, sb0.y, sb0.z));   // glm::normalize(normal) (:300), per triangle
-        const v3p tcol = join3(V3(sa1.x, sa1.y, sa1.z), V3(sb1.x, sb1.y, sb1.z));
         v3p result = splat3(V3(0.0f, 0.0f, 0.0f)), result2 = result;
         for (int k = 0; k < f.nlights; k++) {
             // DirectLight's term before the shadow test (raytracer.cpp:294-304), both pixels at once
@@ -285,6 +284,9 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
             result = add3p(result, D);                                       // :319
             if ((k + 1) % f.samples == 0) result2 = add3p(result2, result);  // :322, after each light's samples
         }
+        // (the triangles' colours only now, out of the LDS table: read beside the normals they were six registers held across the lights' loop)
+        const float4 sa1 = tb.shade[2 * s0 + 1], sb1 = tb.shade[2 * s1 + 1];
+        const v3p tcol = join3(V3(sa1.x, sa1.y, sa1.z), V3(sb1.x, sb1.y, sb1.z));
         const v3p Dl = mul3p(result2, tcol);                                 // :325-326
         const v3p shaded = add3p(avg, mul3p(tcol, add3p(Dl, splat3(ld3(f.indirect)))));   // :584-591 (avgColor += R)
         avg = join3(hit0 ? half0(shaded) : half0(avg), hit1 ? half1(shaded) : half1(avg));
