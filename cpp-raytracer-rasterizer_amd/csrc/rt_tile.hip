@@ -226,6 +226,23 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
     }
     const bool hit0 = ok0 && any0, hit1 = ok1 && any1;
     count_hits(f, (unsigned long long)(__popcll(__ballot(hit0)) + __popcll(__ballot(hit1))));
+    if constexpr (!AA) {
+        // Without supersampling the records are final here: the planes that carry them -- index, focal distance, the Intersection of the
+        // `_ex` calls -- are written now instead of with the colour at the end, so that distance and hit point (eight registers for
+        // outputs most callers do not ask for) are not held across the lights' loop.
+        if (ok0) {
+            const size_t px = (size_t)ya * f.W + x;
+            if (f.index) f.index[px] = bi0;
+            if (f.fd) f.fd[px] = bi0 >= 0 ? bd0 - f.focal_plane : 0.0f;            // focalDistances (:248-249)
+            store_intersection(f, px, bi0, bd0, pos0);
+        }
+        if (ok1) {
+            const size_t px = (size_t)yb * f.W + x;
+            if (f.index) f.index[px] = bi1;
+            if (f.fd) f.fd[px] = bi1 >= 0 ? bd1 - f.focal_plane : 0.0f;
+            store_intersection(f, px, bi1, bd1, pos1);
+        }
+    }
 
     if (__any(hit0 || hit1)) {
         const v3p pos = join3(pos0, pos1);                                   // the record carried across sub-rays (:243-247)
@@ -285,7 +302,10 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
             if ((k + 1) % f.samples == 0) result2 = add3p(result2, result);  // :322, after each light's samples
         }
         // (the triangles' colours only now, out of the LDS table: read beside the normals they were six registers held across the lights' loop)
-        const float4 sa1 = tb.shade[2 * s0 + 1], sb1 = tb.shade[2 * s1 + 1];
+        // (their rows' addresses derived afresh from the records: held, they would be two more registers across the loop)
+        int c0 = bi0 >= 0 ? bi0 : 0, c1 = bi1 >= 0 ? bi1 : 0;
+        asm volatile("" : "+v"(c0), "+v"(c1));
+        const float4 sa1 = tb.shade[2 * c0 + 1], sb1 = tb.shade[2 * c1 + 1];
         const v3p tcol = join3(V3(sa1.x, sa1.y, sa1.z), V3(sb1.x, sb1.y, sb1.z));
         const v3p Dl = mul3p(result2, tcol);                                 // :325-326
         const v3p shaded = add3p(avg, mul3p(tcol, add3p(Dl, splat3(ld3(f.indirect)))));   // :584-591 (avgColor += R)
@@ -300,33 +320,42 @@ __device__ __forceinline__ void tile_body2(const RtTileFrame &tf, int tx, int ty
         const f2 q = splat2((float)(rs * rs));
         avg = V3P(div2(avg.x, q), div2(avg.y, q), div2(avg.z, q));
     }
-    if (ok0) {
+    // (the pixel's coordinates again, from the lane's number as the hardware counts it: two instructions instead of three registers
+    // held from the top of the body to here -- with the planes above, what kept the kernel a register short of six waves per SIMD)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int xe = x0 + (lane_e % TW), yae = y0 + (lane_e / TW), ybe = yae + TH;
+    const bool ok0e = xe < f.W && yae < f.y1, ok1e = xe < f.W && ybe < f.y1;
+    if (ok0e) {
         const v3 c = half0(avg);
-        const size_t px = (size_t)ya * f.W + x;
+        const size_t px = (size_t)yae * f.W + xe;
         if (f.rgb) st3(f.rgb + 3 * px, c);
-        if (f.index) f.index[px] = bi0;
-        if (f.fd) f.fd[px] = bi0 >= 0 ? bd0 - f.focal_plane : 0.0f;            // focalDistances (:248-249)
-        store_intersection(f, px, bi0, bd0, pos0);
-        if (x >= 1 && x < f.W - 1 && ya >= 1 && ya < f.H - 1)                // :618-620
-            f.xrgb[(size_t)(ya - f.row_origin) * f.pitch_words + x] = pack_xrgb(c);
+        if constexpr (AA) {
+            if (f.index) f.index[px] = bi0;
+            if (f.fd) f.fd[px] = bi0 >= 0 ? bd0 - f.focal_plane : 0.0f;        // focalDistances (:248-249)
+            store_intersection(f, px, bi0, bd0, pos0);
+        }
+        if (xe >= 1 && xe < f.W - 1 && yae >= 1 && yae < f.H - 1)            // :618-620
+            f.xrgb[(size_t)(yae - f.row_origin) * f.pitch_words + xe] = pack_xrgb(c);
     }
-    if (ok1) {
+    if (ok1e) {
         const v3 c = half1(avg);
-        const size_t px = (size_t)yb * f.W + x;
+        const size_t px = (size_t)ybe * f.W + xe;
         if (f.rgb) st3(f.rgb + 3 * px, c);
-        if (f.index) f.index[px] = bi1;
-        if (f.fd) f.fd[px] = bi1 >= 0 ? bd1 - f.focal_plane : 0.0f;
-        store_intersection(f, px, bi1, bd1, pos1);
-        if (x >= 1 && x < f.W - 1 && yb >= 1 && yb < f.H - 1)
-            f.xrgb[(size_t)(yb - f.row_origin) * f.pitch_words + x] = pack_xrgb(c);
+        if constexpr (AA) {
+            if (f.index) f.index[px] = bi1;
+            if (f.fd) f.fd[px] = bi1 >= 0 ? bd1 - f.focal_plane : 0.0f;
+            store_intersection(f, px, bi1, bd1, pos1);
+        }
+        if (xe >= 1 && xe < f.W - 1 && ybe >= 1 && ybe < f.H - 1)
+            f.xrgb[(size_t)(ybe - f.row_origin) * f.pitch_words + xe] = pack_xrgb(c);
     }
 }
 
 template <int TW, bool AA>
 #ifndef MIRT_TILE_WAVES
-#define MIRT_TILE_WAVES 5
+#define MIRT_TILE_WAVES 6
 #endif
-// (five waves per SIMD -- 89 VGPRs -- without supersampling; the supersampling instantiation carries a second set of sub-ray state)
+// (six waves per SIMD -- 79 VGPRs -- without supersampling; the supersampling instantiation, which carries a second set of sub-ray state, four)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AA ? 3 : MIRT_TILE_WAVES, AA ? 4 : MIRT_TILE_WAVES))) void k_rt_tile2(const RtTileFrame tf)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_all[];
