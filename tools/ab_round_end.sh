@@ -1,10 +1,10 @@
 set -uo pipefail
-V=cpp-raytracer-rasterizer_amd/build/variants
 {
-echo "== raster4k: base; even split of k_raster_small's items over the waves, 5 / 6 / 8 workgroups per CU; base with 4"
-python tools/frame_variant.py raster4k $V/libmirt_even.so
-MIRT_SMALL_WGS_PER_CU=6 python tools/frame_variant.py raster4k $V/libmirt_even.so
-MIRT_SMALL_WGS_PER_CU=8 python tools/frame_variant.py raster4k $V/libmirt_even.so
-MIRT_SMALL_WGS_PER_CU=4 python tools/frame_variant.py raster4k $V/libmirt_even.so
-} > gpurun_out/ab2.txt 2>&1
-cat gpurun_out/ab2.txt
+for v in 0 1; do
+echo "== HIP_FORCE_DEV_KERNARG=$v"
+HIP_FORCE_DEV_KERNARG=$v python tools/moving_ab.py soup100k
+HIP_FORCE_DEV_KERNARG=$v python tools/frame_variant.py raster4k
+HIP_FORCE_DEV_KERNARG=$v python tools/frame_variant.py cornell1080
+done
+} > gpurun_out/ab3.txt 2>&1
+cat gpurun_out/ab3.txt
