@@ -666,7 +666,7 @@ def run_workload(env, name, steps, warmup, mode_name, moving, want_cpu, target_s
                            "parallelism": ("bands%d%s+%s" % (world, "(cost-weighted)" if weighted else "", "rccl-p2p-gather(libmirt)" if native else "torch-gather") + ("x%d" % batch if batch > 1 else "")) if world > 1 else "1gpu"},
             })
             kt = kernel_ms.get("trace", 0.0)
-            kname = {mirt.RT_BRUTE: ("k_rt_tile<" if aa > 1 else "k_rt_tile2") if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
+            kname = {mirt.RT_BRUTE: "k_rt_tile2" if len(tris) <= 64 else ("k_rt_small" if len(tris) * 48 * 3 + 16 <= 48 * 1024 else "k_rt_brute"),
                      mirt.RT_BINNED: "k_rt_trace2"}[st["mode_used"]]
             # algorithmic flops per launch = ray-triangle tests the launch executed x 60 flop per test as written in the
             # reference (brute force: rays x triangles; tile / binned kernels: filter evaluations counted in-kernel)

@@ -25,7 +25,7 @@ for doc, name in ((traffic, "hbm_traffic"), (issue, "pmc_issue")):
         old = json.load(open(path))
         doc["workloads"].update(old.get("workloads", {}))
         doc["stamps"].update(old.get("stamps", {}))
-for t in ("cornell1080", "soup100k", "raster4k", "soup1m8k", "raster4kdof8", "cornell1080dof8"):
+for t in ("cornell1080", "soup100k", "raster4k", "soup1m8k", "raster4kdof8", "cornell1080dof8", "cornell1080soft16", "cornell1080aa3", "cornell500"):
     stats = sorted(glob.glob("gpurun_out/prof_%s/trace/*/*_kernel_stats.csv" % t), key=os.path.getmtime)
     if stats:
         shutil.copy(stats[-1], "profiles/%s_rocprof_%s_kernel_stats.csv" % (tag, t))
