@@ -283,7 +283,11 @@ MIRT_API int mirt_band_of(int rank, int world, int height, int *y0, int *y1);
  * of pieces (writes at most max_pieces; arrays nullable).  Pure arithmetic, no device needed. */
 MIRT_API int mirt_band_plan(int world, int root, int width, int height, int nviews, uint64_t *root_offset, uint64_t *band_offset,
                             uint64_t *bytes, int32_t *peer, int max_pieces);
-/* The partition of a sharded frame among the ranks (every rank must set the same; default 0):
+/* The partition of a sharded frame among the ranks (every rank must set the same; default 0).  The setting belongs to the library's
+ * context: mirt_shutdown() puts it back to 0, so set it after mirt_init().  Nothing exchanges or verifies it: ranks with different strip
+ * heights build different gather plans and the grouped send / receive then mismatches (RCCL waits instead of failing) -- the weighted
+ * partition has no per-rank parameter to disagree about and is what bench.py uses for binned frames.
+ *
  *   strip_rows == 0   contiguous bands (mirt_band_of): one binning pass and one launch chain per rank and frame -- the right
  *                     choice for the binned ray tracer, whose per-frame cost has a part that does not shrink with the rows;
  *   strip_rows  > 0   interleaved strips of that many rows (a multiple of 8), strip s to rank s % world: every rank samples the
