@@ -28,3 +28,16 @@ def test_collection_scripts_name_existing_tools():
         text = open(os.path.join(ROOT, "tools", name)).read()
         for ref in set(re.findall(r"tools/([A-Za-z0-9_]+\.(?:py|sh))", text)):
             assert os.path.exists(os.path.join(ROOT, "tools", ref)), (name, ref)
+
+
+def test_reference_build_products_stay_out_of_history_but_travel():
+    """oracle/_ref/ (the reference's functions compiled in the build container) is git-ignored, so no reference product enters
+    the history, and NOT gpurun-ignored, so the built libraries reach the GPU box like the other built .so files."""
+    ignored = [l.strip() for l in open(os.path.join(ROOT, ".gitignore")) if l.strip() and not l.startswith("#")]
+    assert "oracle/_ref/" in ignored
+    p = os.path.join(ROOT, ".gpurunignore")
+    if os.path.exists(p):
+        assert not any("oracle/_ref" in l for l in open(p) if not l.startswith("#"))
+    r = subprocess.run(["git", "-C", ROOT, "ls-files", "oracle/_ref"], capture_output=True, text=True)
+    if r.returncode == 0:           # an exported tree has no .git: nothing to check there
+        assert r.stdout.strip() == ""
